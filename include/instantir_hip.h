@@ -1,0 +1,145 @@
+/* libinstantir_hip.so -- C ABI of the MI355X (gfx950) kernels behind the InstantIR denoising path.
+ *
+ * The reference (rebots-online/InstantIR) is pure Python on PyTorch ops; it has no FFI of its own
+ * (SURVEY.md section 8b).  Each entry point below therefore replaces a *call site* of a PyTorch op in
+ * the reference and cites it.  Conventions: plain C symbols, raw device pointers, explicit
+ * dims/strides (element counts, fp16 unless noted), `stream` is a hipStream_t passed as void*,
+ * caller owns every buffer, return 0 on success, IIR_EINVAL (-1) for rejected arguments,
+ * IIR_ELAUNCH (-2) when the launch failed.  No global state besides one-time kernel attributes;
+ * thread-safe per stream; nothing here allocates, synchronises or copies, so every entry point may
+ * be captured into a hipGraph.
+ *
+ * Activation layout is NHWC / (rows, tokens, channels): a (R, C, H, W) reference tensor is the
+ * (R, H, W, C) buffer here, which is also the (R, H*W, C) token matrix (reference permutes at
+ * module/min_sdxl.py:581-583,590-594 -- free here).
+ */
+#ifndef INSTANTIR_HIP_H
+#define INSTANTIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IIR_ABI_VERSION 1
+
+/* epilogue selectors */
+#define IIR_EPI_PLAIN 0 /* C = act(acc + bias + rowbias) + res                                    */
+#define IIR_EPI_GEGLU 1 /* C[:, j] = (acc_v + b_v) * gelu_erf(acc_g + b_g); W rows pair-permuted  */
+#define IIR_EPI_SFT 2   /* C[:, j] = res[:, j] * (acc_gamma + b + 1) + (acc_beta + b)             */
+#define IIR_ACT_NONE 0
+#define IIR_ACT_SILU 1
+
+/* Pair permutation expected by GEGLU / SFT epilogues: for an op with `n_out` outputs whose
+ * "value" rows are V[0..n_out) and partner rows are G[0..n_out), the weight (and bias) handed to
+ * the kernel has 2*n_out rows where rows [32*b, 32*b+16) = V[16*b, 16*b+16) and
+ * rows [32*b+16, 32*b+32) = G[16*b, 16*b+16).  (Host helper: instantir_amd.packing.pair_rows.) */
+
+typedef struct iir_gemm_desc {
+    const void* A; int64_t lda;    /* [M][K] activations, row stride lda                           */
+    const void* W;                 /* [N][K] weights (torch nn.Linear layout), K contiguous        */
+    void* C; int64_t ldc;          /* [M][N] (or [M][N/2] for paired epilogues)                    */
+    int32_t M, N, K;               /* K % 64 == 0, N % 4 == 0                                      */
+    const void* bias;              /* [N] or NULL                                                  */
+    const void* rowbias; int64_t ldrb; int32_t rows_per_rb; /* + rowbias[m / rows_per_rb][n]       */
+    const void* res; int64_t ldr;  /* residual / SFT `h` input, or NULL                            */
+    int32_t epi, act;
+    float out_scale;               /* 0 means 1                                                    */
+    int32_t tile;                  /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64                   */
+} iir_gemm_desc;
+
+/* Replaces nn.Linear / F.linear call sites: attention projections
+ * module/ip_adapter/attention_processor.py:370,377-378,402,1140,1148-1149,1173-1174,1195; GEGLU
+ * feed-forward module/min_sdxl.py:502-528; proj_in/out :572,575; time_emb_proj :266; embeddings
+ * :226-240; AdaLayerNorm linear attention_processor.py:23; Resampler resampler.py:48-49,66-68,95-97. */
+int iir_gemm_f16(const iir_gemm_desc* d, void* stream);
+
+typedef struct iir_conv_desc {
+    const void* X; int64_t ldx;    /* NHWC input (R, H, W, Cin), pixel stride ldx >= Cin           */
+    int32_t R, H, Wd, Cin;         /* image count, height, width; Cin % 64 == 0 (host pads latents) */
+    const void* Wt;                /* [Cout][k][k][Cin] weights                                    */
+    void* Y; int64_t ldy;          /* NHWC output, pixel stride ldy                                */
+    int32_t Cout, ksize, stride, upsample;   /* ksize 1|3, stride 1|2, nearest-2x folded if upsample */
+    const void* bias;
+    const void* rowbias; int64_t ldrb; int32_t rows_per_rb;
+    const void* res; int64_t ldr;
+    int32_t epi, act;
+    float out_scale;
+    int32_t tile;
+    const void* zero_page;         /* >= 128 zero bytes: source of the padding pixels              */
+} iir_conv_desc;
+
+/* Replaces nn.Conv2d call sites: ResnetBlock2D module/min_sdxl.py:256-259,274 (+ the temb add :267 as
+ * `rowbias`, the residual add :279 as `res`), Downsample2D :601-606, Upsample2D :612-618 (with
+ * F.interpolate nearest folded in), conv_in/conv_out :827,912, SFT module/aggregator.py:62-67,76-86. */
+int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream);
+
+typedef struct iir_attn_kv {
+    const void* K; int64_t ldk, k_batch_stride;     /* K[b][t][h*64+d]                               */
+    const void* Vt; int64_t ldvt, vt_batch_stride;  /* Vt[h*64+d][b*vt_batch_stride + t]; rows finite */
+    int32_t Tkv;                                    /*   and readable on [0, roundup8(Tkv))           */
+} iir_attn_kv;
+
+typedef struct iir_attn_desc {
+    const void* Q; int64_t ldq, q_batch_stride;     /* Q[b][t][h*64+d]                               */
+    void* O; int64_t ldo, o_batch_stride;           /* O[b][t][h*64+d]                               */
+    int32_t batch, heads, Tq, nseg;                 /* nseg 1 or 2                                   */
+    float scale;                                    /* 1/sqrt(64) for SDPA                           */
+    iir_attn_kv kv[2];
+} iir_attn_desc;
+
+/* Replaces F.scaled_dot_product_attention at module/ip_adapter/attention_processor.py:394 (nseg=1)
+ * and the two SDPA calls + add at :1165,:1185,:1192 (nseg=2: text KV, IP KV), head_dim 64. */
+int iir_attention_d64_f16(const iir_attn_desc* a, void* stream);
+
+/* nn.GroupNorm (+ fused nn.SiLU) on NHWC: module/min_sdxl.py:245,252,257,269-271,568,841.
+ * workspace: iir_groupnorm_workspace_bytes(R, groups) bytes of fp32 partial sums. */
+int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
+                           int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups);
+
+/* nn.LayerNorm (module/min_sdxl.py:534-538; resampler.py:15,43-44,98) and AdaLayerNorm's
+ * LN(x)*(1+scale)+shift (attention_processor.py:24-25).  gamma/beta/shift/scale may be NULL.
+ * transposed != 0 stores y^T (used to emit the IP-adapter V^T image directly):
+ *   Y[c][ (row / tr_rows) * tr_bstride + row % tr_rows ], row stride ldy. */
+int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t rows, int32_t C, const void* gamma,
+                      const void* beta, float eps, const void* shift, const void* scale, int64_t ldmod,
+                      int32_t rows_per_mod, int32_t transposed, int32_t tr_rows, int64_t tr_bstride, void* stream);
+
+/* Timesteps: module/min_sdxl.py:205-224.  out[r][col_off + v*dim + ...] = [cos | sin](vals[r][v] * w_k). */
+int iir_sinusoid_f16(const float* vals, int32_t n_vals, int32_t rows, int32_t dim, void* out, int64_t ldo,
+                     int32_t col_off, void* stream);
+int iir_silu_f16(const void* x, void* y, int64_t n, void* stream);
+
+/* dst[m][dst_off + c] = src[m][c] + add[m][c] * add_scale[m / rows_per_scale]: torch.cat of skips
+ * (module/min_sdxl.py:712) with the aggregator residual scaling/add folded in
+ * (pipelines/sdxl_instantir.py:1602-1603). add / add_scale may be NULL. */
+int iir_copy_add_f16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t dst_off, int64_t M, int32_t C,
+                     const void* add, int64_t lda, const float* add_scale, int32_t rows_per_scale, void* stream);
+
+/* fp32 NCHW latents <-> fp16 NHWC rows (pipelines/sdxl_instantir.py:1503 cat([latents]*2) = rep 2). */
+int iir_pack_latent(const float* x, int32_t B, int32_t C, int32_t HW, void* out, int64_t ldo, int32_t rep, float scale,
+                    void* stream);
+int iir_unpack_latent(const void* in, int64_t ldi, int32_t R, int32_t C, int32_t HW, float* out, void* stream);
+
+/* CFG + main scheduler step (pipelines/sdxl_instantir.py:1619-1633).  coef = device fp32[8]:
+ * {guidance, sqrt(1-abar_t), sqrt(abar_t), k_x0, k_x, k_eps, k_noise, 0}; prev = k_x0*x0 + k_x*x + k_eps*eps
+ * + k_noise*noise with x0 = (x - sqrt(1-abar_t)*eps)/sqrt(abar_t).  DDPM: k_eps = 0; DDIM: k_x = 0. */
+int iir_sched_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int32_t HW, int32_t cfg, const float* coef,
+                   const float* x, const float* noise, float* prev, float* x0_out, float* eps_out, void* stream);
+
+/* LCMSingleStepScheduler.step, schedulers/lcm_single_step_scheduler.py:455-484.
+ * coef = device fp32[4] {sqrt(1-abar_t), sqrt(abar_t), c_out, c_skip}. */
+int iir_lcm_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t rep, int32_t C, int32_t HW, const float* coef,
+                 const float* x, void* out_nhwc, int64_t ldo, float* out_nchw, void* stream);
+
+int iir_transpose_f16(const void* in, int64_t ldi, int32_t rows, int32_t cols, void* out, int64_t ldo, int32_t rows_pad,
+                      void* stream);
+int iir_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,220 @@
+// K3/K4: flash-style attention for head_dim 64, fp16 in / fp32 softmax + accumulate, gfx950.
+//
+// Replaces F.scaled_dot_product_attention at module/ip_adapter/attention_processor.py:394
+// (AttnProcessor2_0, self-attention) and the PAIR of SDPA calls sharing one query at :1165 and :1185
+// (TA_IPAttnProcessor2_0: text KV + IP-adapter KV, outputs summed with scale 1.0 at :1192).  Up to
+// two KV segments are processed in one pass over Q: out = softmax(Q K1^T) V1 + softmax(Q K2^T) V2.
+//
+// Layout: Q, K are token-major with heads side by side in a row (row strides given, so they can be
+// column slices of a fused QKV GEMM output).  V is consumed TRANSPOSED: Vt[(h*64+d)][token]; the V
+// projection is issued as the GEMM  Vt = Wv . X^T  (operands swapped), which costs nothing extra.
+// Contract: each Vt row is readable and finite on columns [0, roundup8(Tkv)) (pad with zeros).
+//
+// Per block: 4 waves x 32 query rows.  Per 64-key tile: S^T = K . Q^T with 32x32x16 MFMA (keys on
+// the accumulator rows, the query on the lane), so row max / row sum are in-lane reductions plus one
+// cross-half exchange, and the exponentiated accumulator registers are, after fp16 packing, directly
+// the B operand of O^T += V^T . P^T (no LDS round trip for P).  K and V^T tiles are staged by
+// global_load_lds_dwordx4 into double-buffered XOR-swizzled LDS images.
+#include "common.h"
+#include "../../include/instantir_hip.h"
+
+namespace {
+
+struct Seg { const f16* K; long ldk, kbs; const f16* Vt; long ldvt, vbs; int Tkv; };
+struct AGeo {
+    const f16* Q; long ldq, qbs;
+    f16* O; long ldo, obs;
+    int Tq, nseg;
+    float c;   // softmax scale * log2(e)
+    Seg seg[2];
+};
+
+constexpr int KT = 64;   // keys per tile
+
+__global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];
+    char* Ks = smem;                    // [2][64 keys][128 B]
+    char* Vs = smem + 2 * KT * 128;     // [2][64 d][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    // Q fragments: B operand of S^T = K.Q^T -- lane (q, hh) holds d = 16*ks + 8*hh + [0,8)
+    f16x8 qf[4];
+    {
+        int q = q0 + qi;
+        if (q >= g.Tq) q = g.Tq - 1;
+        const f16* qp = g.Q + (long)b * g.qbs + (long)q * g.ldq + h * 64 + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
+    }
+
+    f32x16 oout[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oout[i][r] = 0.f;
+
+    const int srow = lane >> 3, spos = lane & 7;
+
+    for (int sg = 0; sg < g.nseg; ++sg) {
+        const Seg s = g.seg[sg];
+        const f16* kbase = s.K + (long)b * s.kbs + h * 64;
+        const f16* vbase = s.Vt + (long)(h * 64) * s.ldvt + (long)b * s.vbs;
+        const int ntiles = (s.Tkv + KT - 1) / KT;
+        const int tpad = (s.Tkv + 7) & ~7;   // contract: Vt rows readable and finite on [0, tpad)
+
+        auto stage = [&](int t, int buf) {
+            // K tile: 8 glds instructions (8 key rows each); V^T tile: 8 (8 d rows each); 2+2 per wave
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r0 = (i * 4 + wave) * 8;
+                int key = t * KT + r0 + srow;
+                if (key >= s.Tkv) key = s.Tkv - 1;
+                const int kc = spos ^ srow;                        // swz(key) = key & 7
+                glds16(kbase + (long)key * s.ldk + kc * 8, Ks + buf * KT * 128 + r0 * 128);
+                const int d = r0 + srow;
+                const int vc = spos ^ ((d >> 1) & 7);              // swz(d) = (d >> 1) & 7
+                int kcol = t * KT + vc * 8;                        // 8 keys per 16-byte chunk
+                if (kcol >= tpad) kcol = 0;                        // chunk fully past the end: all its keys are masked
+                glds16(vbase + (long)d * s.ldvt + kcol, Vs + buf * KT * 128 + r0 * 128);
+            }
+        };
+
+        float m = -INFINITY, l = 0.f;
+        f32x16 o[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+
+        stage(0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+
+        for (int t = 0; t < ntiles; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+            const char* kt = Ks + buf * KT * 128;
+            const char* vt = Vs + buf * KT * 128;
+
+            // ---- S^T = K . Q^T  (2 blocks of 32 keys)
+            f32x16 sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f16x8 kf = *(const f16x8*)(kt + (kb * 32 + qi) * 128 + (((2 * ks + hh) ^ (qi & 7)) * 16));
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                }
+            }
+            // ---- tail mask (last tile only; wave-uniform branch)
+            if ((t + 1) * KT > s.Tkv) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (key >= s.Tkv) sacc[kb][r] = -INFINITY;
+                    }
+            }
+            // ---- online softmax (base 2)
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx * g.c);
+            const float alpha = exp2f(m - m_new);
+            float lsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(fmaf(sacc[kb][r], g.c, -m_new));
+                    sacc[kb][r] = p;
+                    lsum += p;
+                }
+            l = l * alpha + lsum;
+            m = m_new;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+            // ---- O^T += V^T . P^T : k-step (kb, sp) covers keys 32kb+16sp+[0,16) in the permuted order
+            //      element j of lane half hh <-> key 16*sp' + 8*(j>>2) + 4*hh + (j&3)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    f16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (f16)sacc[kb][8 * sp + j];
+                    const int key_lo = kb * 32 + sp * 16 + 4 * hh;           // 4 keys, then 4 more at +8
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const int d = db * 32 + qi;
+                        const int sw = (d >> 1) & 7;
+                        const char* row = vt + d * 128;
+                        const f16x4 lo = *(const f16x4*)(row + (((key_lo >> 3) ^ sw) * 16) + (key_lo & 7) * 2);
+                        const f16x4 hi = *(const f16x4*)(row + ((((key_lo + 8) >> 3) ^ sw) * 16) + (key_lo & 7) * 2);
+                        f16x8 vf;
+                        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[db], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        }
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / ltot;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oout[i][r] += o[i][r] * inv;
+    }
+
+    // ---- store: lane (q, hh) holds d = 32*db + 8*gq + 4*hh + [0,4) in regs 4*gq..4*gq+3
+    const int q = q0 + qi;
+    if (q < g.Tq) {
+        f16* op = g.O + (long)b * g.obs + (long)q * g.ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                f16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (f16)oout[db][4 * gq + j];
+                *(f16x4*)(op + db * 32 + gq * 8 + hh * 4) = v;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
+    if (!a || !a->Q || !a->O || a->nseg < 1 || a->nseg > 2) return IIR_EINVAL;
+    if (a->Tq <= 0 || a->heads <= 0 || a->batch <= 0) return IIR_EINVAL;
+    if (a->ldq % 8 || a->ldo % 4) return IIR_EINVAL;
+    AGeo g{};
+    g.Q = (const f16*)a->Q; g.ldq = a->ldq; g.qbs = a->q_batch_stride;
+    g.O = (f16*)a->O; g.ldo = a->ldo; g.obs = a->o_batch_stride;
+    g.Tq = a->Tq; g.nseg = a->nseg;
+    g.c = a->scale * 1.4426950408889634f;
+    for (int i = 0; i < a->nseg; ++i) {
+        const iir_attn_kv* s = &a->kv[i];
+        if (!s->K || !s->Vt || s->Tkv <= 0 || s->ldk % 8 || s->ldvt % 8 || s->vt_batch_stride % 8) return IIR_EINVAL;
+        g.seg[i] = Seg{(const f16*)s->K, s->ldk, s->k_batch_stride, (const f16*)s->Vt, s->ldvt, s->vt_batch_stride, s->Tkv};
+    }
+    const dim3 grid((a->Tq + 127) / 128, a->heads, a->batch);
+    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    return iir_launch_status();
+}

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libinstantir_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../libinstantir_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -w"
+mkdir -p build
+pids=()
+for f in gemm_conv attention norm; do
+  hipcc $FLAGS -c $f.hip -o build/$f.o &
+  pids+=($!)
+done
+hipcc $FLAGS -ffp-contract=off -c pointwise.hip -o build/pointwise.o &
+pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm_conv.o build/attention.o build/norm.o build/pointwise.o
+echo "built $(realpath $OUT)"

@@ -1,0 +1,289 @@
+// K1/K2/K7/K8: fp16 MFMA GEMM and implicit-GEMM convolution (NHWC) with fused epilogues, gfx950.
+//
+// Replaces on the reference's hot path: every nn.Linear call site of the UNet /
+// Aggregator / adapters (module/ip_adapter/attention_processor.py:370,377-378,402,1140,1148-1149,
+// 1173-1174,1195; GEGLU FF per module/min_sdxl.py:502-528), every 3x3 / 1x1 nn.Conv2d
+// (ResnetBlock2D module/min_sdxl.py:242-283, Down/Upsample2D :598-618, SFT module/aggregator.py:70-90).
+//
+// Math: C[m][n] = epi( sum_k A[m][k] * W[n][k] ), fp16 operands, fp32 accumulate (MFMA 16x16x32 f16).
+//   GEMM : A is [M][K] row-major (lda), W is [N][K] (torch Linear layout).
+//   CONV : A row m = output pixel (img, oy, ox) of an NHWC tensor, k = (ky*ks+kx)*Cin + c; the A tile
+//          is gathered straight from the input image (zero page for padding) -- no im2col buffer.
+//          W is [Cout][ks][ks][Cin].  stride 1/2; `ups` folds a nearest-2x upsample into the gather.
+//
+// Structure (v1): BMxBNx64 block tile, 4 waves (2x2), operands staged by global_load_lds_dwordx4
+// into a double-buffered, XOR-swizzled LDS image (swizzle applied on the per-lane SOURCE address so
+// the LDS write stays lane-linear), fragments by ds_read_b128, XCD-aware tile order.
+// The weight fragment is the MFMA "A" operand so each lane ends up with 4 consecutive output
+// columns of one row -> 8-byte packed stores and 8-byte bias/residual loads in the epilogue.
+#include "common.h"
+#include "../../include/instantir_hip.h"
+
+namespace {
+
+constexpr int BK = 64;   // halfs per K tile = one 128-byte LDS row
+
+struct Geo {   // per-launch constants shared by GEMM and CONV paths
+    const f16* A; long lda;
+    const f16* W;
+    f16* C; long ldc;
+    int M, N, K;
+    const f16* bias;
+    const f16* rowbias; long ldrb; int rows_per_rb;
+    const f16* res; long ldr;
+    int epi, act;
+    float out_scale;
+    // conv
+    int H, Wd, Cin, Ho, Wo, ks, stride, pad, ups;
+    const f16* zero;
+    int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
+    constexpr int WM = BM / 2, WN = BN / 2;      // wave tile
+    constexpr int MI = WM / 16, NI = WN / 16;    // 16x16 MFMA tiles per wave
+    constexpr int A_INST = BM / 32, B_INST = BN / 32;   // glds instructions per wave per K tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* As = (f16*)smem;                       // [2][BM][64]
+    f16* Bs = As + 2 * BM * BK;                 // [2][BN][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order (blocks b, b+8, ... share an XCD/L2): give each XCD a contiguous run of
+    // tiles that walks M fastest, so co-resident blocks of one XCD share the same weight panel.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int tm = bid % g.tiles_m, tn = bid / g.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-lane staging addresses -------------------------------------------------------------
+    const int srow = lane >> 3;                       // row inside an 8-row glds instruction
+    const int schunk = (lane & 7) ^ srow;             // swizzled 16-byte chunk fetched by this lane
+    const f16* a_src[A_INST];
+    int a_pix_y[A_INST], a_pix_x[A_INST];             // conv: output pixel coords (input domain origin)
+    const f16* a_img[A_INST];
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        int m = m0 + (i * 4 + wave) * 8 + srow;
+        if (m >= g.M) m = g.M - 1;                    // clamp: tail rows are computed and discarded
+        if (!CONV) {
+            a_src[i] = g.A + (long)m * g.lda + schunk * 8;
+        } else {
+            const int hw = g.Ho * g.Wo;
+            const int img = m / hw, rem = m - img * hw;
+            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            a_img[i] = g.A + (long)img * g.H * g.Wd * g.lda + schunk * 8;
+            a_pix_y[i] = oy * g.stride - g.pad;
+            a_pix_x[i] = ox * g.stride - g.pad;
+        }
+    }
+    const f16* b_src[B_INST];
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+        int n = n0 + (i * 4 + wave) * 8 + srow;
+        if (n >= g.N) n = g.N - 1;
+        b_src[i] = g.W + (long)n * g.K + schunk * 8;
+    }
+
+    auto stage = [&](int kt, int buf) {
+        f16* as = As + buf * BM * BK;
+        f16* bs = Bs + buf * BN * BK;
+        const int k0 = kt * BK;
+        if (!CONV) {
+#pragma unroll
+            for (int i = 0; i < A_INST; ++i) glds16(a_src[i] + k0, as + (i * 4 + wave) * 8 * BK);
+        } else {
+            const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+            const int ky = tap / g.ks, kx = tap - ky * g.ks;
+#pragma unroll
+            for (int i = 0; i < A_INST; ++i) {
+                int iy = a_pix_y[i] + ky, ix = a_pix_x[i] + kx;
+                const f16* p;
+                if (g.ups) {   // coordinates are in the 2x-upsampled domain
+                    const bool ok = (iy >= 0) & (iy < 2 * g.H) & (ix >= 0) & (ix < 2 * g.Wd);
+                    p = ok ? a_img[i] + ((long)(iy >> 1) * g.Wd + (ix >> 1)) * g.lda + c0 : g.zero + (lane & 7) * 8;
+                } else {
+                    const bool ok = (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.Wd);
+                    p = ok ? a_img[i] + ((long)iy * g.Wd + ix) * g.lda + c0 : g.zero + (lane & 7) * 8;
+                }
+                glds16(p, as + (i * 4 + wave) * 8 * BK);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_INST; ++i) glds16(b_src[i] + k0, bs + (i * 4 + wave) * 8 * BK);
+    };
+
+    // ---- fragment read offsets (bytes inside a tile image) --------------------------------------
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[2], b_off[2];   // per k-step, for tile row (w*W? + i*16 + frow)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int phys = (s * 4 + fq) ^ (frow & 7);
+        a_off[s] = (wm * WM + frow) * 128 + phys * 16;
+        b_off[s] = (wn * WN + frow) * 128 + phys * 16;
+    }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only (gfx9: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8])
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const char* as = (const char*)(As + cur * BM * BK);
+        const char* bs = (const char*)(Bs + cur * BN * BK);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const f16x8*)(as + a_off[s] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = *(const f16x8*)(bs + b_off[s] + j * 16 * 128);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's glds for tile kt+1 have landed
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds row m = ..+frow, 4 consecutive columns n = ..+4*fq+{0..3} ---------
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WM + i * 16 + frow;
+        if (m >= g.M) continue;
+        const f16* rb = g.rowbias ? g.rowbias + (long)(m / g.rows_per_rb) * g.ldrb : nullptr;
+        if (g.epi == IIR_EPI_PLAIN) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * WN + j * 16 + fq * 4;
+                if (n >= g.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (g.bias) { f16x4 b = *(const f16x4*)(g.bias + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
+                if (rb) { f16x4 b = *(const f16x4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
+                if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
+                if (g.res) { f16x4 r = *(const f16x4*)(g.res + (long)m * g.ldr + n); for (int t = 0; t < 4; ++t) v[t] += (float)r[t]; }
+                f16x4 o;
+                for (int t = 0; t < 4; ++t) o[t] = (f16)(v[t] * g.out_scale);
+                *(f16x4*)(g.C + (long)m * g.ldc + n) = o;
+            }
+        } else {
+            // paired columns: in every 32-column group of the (row-permuted) weight the first 16 are
+            // the "value" rows and the next 16 their partners (gate for GEGLU; beta for SFT).
+#pragma unroll
+            for (int j = 0; j < NI; j += 2) {
+                const int n = n0 + wn * WN + j * 16 + fq * 4;          // permuted column of the value
+                if (n >= g.N) continue;
+                const int no = (n0 + wn * WN + j * 16) / 2 + fq * 4;    // output column
+                float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float b[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                if (g.bias) {
+                    f16x4 ba = *(const f16x4*)(g.bias + n), bb = *(const f16x4*)(g.bias + n + 16);
+                    for (int t = 0; t < 4; ++t) { a[t] += (float)ba[t]; b[t] += (float)bb[t]; }
+                }
+                f16x4 o;
+                if (g.epi == IIR_EPI_GEGLU) {
+                    for (int t = 0; t < 4; ++t) o[t] = (f16)(a[t] * gelu_erf_f(b[t]));
+                } else {   // IIR_EPI_SFT: h * (gamma + 1) + beta, h from `res`
+                    f16x4 h = *(const f16x4*)(g.res + (long)m * g.ldr + no);
+                    for (int t = 0; t < 4; ++t) o[t] = (f16)((float)h[t] * (a[t] + 1.0f) + b[t]);
+                }
+                *(f16x4*)(g.C + (long)m * g.ldc + no) = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch(const Geo& g0, bool conv, hipStream_t stream) {
+    Geo g = g0;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const size_t lds = 2 * (BM + BN) * BK * sizeof(f16);
+    const dim3 grid(g.tiles_m * g.tiles_n), block(256);
+    if (conv) {
+        static bool attr_c = false;
+        if (!attr_c) { hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, block, lds, stream, g);
+    } else {
+        static bool attr_g = false;
+        if (!attr_g) { hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, lds, stream, g);
+    }
+    return iir_launch_status();
+}
+
+int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
+    // tile: 0 = auto.  Auto picks the largest tile that still yields >= ~1.5 waves of blocks on
+    // 256 CUs (2 blocks/CU resident); the paired epilogues need BN >= 64 (NI even).
+    if (tile == 0) {
+        auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
+        if (blocks(128, 128) >= 384) tile = 1;
+        else if (blocks(128, 64) >= 256) tile = 2;
+        else tile = 3;
+    }
+    switch (tile) {
+        case 1: return launch<128, 128>(g, conv, stream);
+        case 2: return launch<128, 64>(g, conv, stream);
+        case 3: return launch<64, 64>(g, conv, stream);
+        default: return IIR_EINVAL;
+    }
+}
+
+}  // namespace
+
+extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
+    if (!d || !d->A || !d->W || !d->C) return IIR_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % BK) return IIR_EINVAL;
+    if (d->N % 4 || d->lda % 8 || d->ldc % 4) return IIR_EINVAL;
+    if (d->epi != IIR_EPI_PLAIN && (d->N % 32)) return IIR_EINVAL;
+    if (d->epi == IIR_EPI_SFT && !d->res) return IIR_EINVAL;
+    if (d->rowbias && d->rows_per_rb <= 0) return IIR_EINVAL;
+    Geo g{};
+    g.A = (const f16*)d->A; g.lda = d->lda; g.W = (const f16*)d->W; g.C = (f16*)d->C; g.ldc = d->ldc;
+    g.M = d->M; g.N = d->N; g.K = d->K;
+    g.bias = (const f16*)d->bias; g.rowbias = (const f16*)d->rowbias; g.ldrb = d->ldrb; g.rows_per_rb = d->rows_per_rb;
+    g.res = (const f16*)d->res; g.ldr = d->ldr; g.epi = d->epi; g.act = d->act;
+    g.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
+    return dispatch(g, false, d->tile, (hipStream_t)stream);
+}
+
+extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
+    if (!c || !c->X || !c->Wt || !c->Y || !c->zero_page) return IIR_EINVAL;
+    if (c->ksize != 3 && c->ksize != 1) return IIR_EINVAL;
+    if (c->Cin % BK || c->ldx % 8 || c->Cout % 4 || c->ldy % 4) return IIR_EINVAL;
+    if (c->stride != 1 && c->stride != 2) return IIR_EINVAL;
+    if (c->upsample && c->stride != 1) return IIR_EINVAL;
+    if (c->epi != IIR_EPI_PLAIN && (c->Cout % 32)) return IIR_EINVAL;
+    if (c->epi == IIR_EPI_SFT && !c->res) return IIR_EINVAL;
+    if (c->rowbias && c->rows_per_rb <= 0) return IIR_EINVAL;
+    const int pad = c->ksize / 2;
+    const int Hin = c->upsample ? 2 * c->H : c->H, Win = c->upsample ? 2 * c->Wd : c->Wd;
+    Geo g{};
+    g.Ho = (Hin + 2 * pad - c->ksize) / c->stride + 1;
+    g.Wo = (Win + 2 * pad - c->ksize) / c->stride + 1;
+    g.A = (const f16*)c->X; g.lda = c->ldx; g.W = (const f16*)c->Wt; g.C = (f16*)c->Y; g.ldc = c->ldy;
+    g.M = c->R * g.Ho * g.Wo; g.N = c->Cout; g.K = c->ksize * c->ksize * c->Cin;
+    g.bias = (const f16*)c->bias; g.rowbias = (const f16*)c->rowbias; g.ldrb = c->ldrb; g.rows_per_rb = c->rows_per_rb;
+    g.res = (const f16*)c->res; g.ldr = c->ldr; g.epi = c->epi; g.act = c->act;
+    g.out_scale = c->out_scale == 0.f ? 1.f : c->out_scale;
+    g.H = c->H; g.Wd = c->Wd; g.Cin = c->Cin; g.ks = c->ksize; g.stride = c->stride; g.pad = pad; g.ups = c->upsample;
+    g.zero = (const f16*)c->zero_page;
+    return dispatch(g, true, c->tile, (hipStream_t)stream);
+}

@@ -1,0 +1,211 @@
+// K5/K6: GroupNorm(+SiLU) over NHWC images and LayerNorm(+adaLN modulation) over token rows.
+// HBM-bound kernels: 16-byte vector accesses, fp32 statistics, wavefront / LDS reductions.
+//
+// Replaces: nn.GroupNorm call sites of ResnetBlock2D (module/min_sdxl.py:245,252; eps 1e-5, SiLU
+// fused: :257,:269-271), Transformer2DModel.norm (:568, eps 1e-6), conv_norm_out (:841); nn.LayerNorm
+// call sites of BasicTransformerBlock (:534-538), Resampler (module/ip_adapter/resampler.py:15,43-44,98)
+// and AdaLayerNorm (module/ip_adapter/attention_processor.py:18-25: LN without affine, eps 1e-6,
+// x * (1 + scale) + shift).
+#include "common.h"
+#include "../../include/instantir_hip.h"
+
+namespace {
+
+constexpr int GN_MAXC = 2560;
+
+// ---- GroupNorm pass 1: per (image, slab, group) partial sum / sum of squares ----------------------
+// grid (nslab, R); each thread owns fixed 8-channel chunks so channel sums live in registers.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* X, long ldx, int HW, int C, int G, int pix_per_slab,
+                                                       float* part /*[R][nslab][G][2]*/) {
+    __shared__ float csum[GN_MAXC], csq[GN_MAXC];
+    const int r = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+    const int nchunk = C >> 3;
+    for (int c = threadIdx.x; c < C; c += 256) { csum[c] = 0.f; csq[c] = 0.f; }
+    __syncthreads();
+    const int p0 = slab * pix_per_slab;
+    const int p1 = min(HW, p0 + pix_per_slab);
+    const f16* base = X + (long)r * HW * ldx;
+    // chunk columns handled by this thread: ch = tid % lanes_c (+ k*lanes_c), rows strided by prow count
+    const int lanes_c = nchunk < 256 ? nchunk : 256;
+    const int prows = 256 / lanes_c;
+    const int tc = threadIdx.x % lanes_c, tp = threadIdx.x / lanes_c;
+    if (tp < prows) {
+        for (int ch = tc; ch < nchunk; ch += lanes_c) {
+            float s[8], q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+            for (int p = p0 + tp; p < p1; p += prows) {
+                const f16x8 v = *(const f16x8*)(base + (long)p * ldx + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&csum[ch * 8 + j], s[j]); atomicAdd(&csq[ch * 8 + j], q[j]); }
+        }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int gi = threadIdx.x; gi < G; gi += 256) {
+        float s = 0.f, q = 0.f;
+        for (int c = gi * cpg; c < (gi + 1) * cpg; ++c) { s += csum[c]; q += csq[c]; }
+        float* o = part + (((long)r * nslab + slab) * G + gi) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+// ---- GroupNorm pass 2: finalize statistics (from the partials) + normalize + affine (+SiLU) ------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, long ldx, f16* Y, long ldy, int HW, int C, int G,
+                                                       int pix_per_blk, const float* part, int nslab, const f16* gamma,
+                                                       const f16* beta, float eps, int silu) {
+    __shared__ float sa[GN_MAXC], sb[GN_MAXC];
+    __shared__ float gmean[64], grstd[64];
+    const int r = blockIdx.y;
+    const int cpg = C / G;
+    if (threadIdx.x < G) {
+        float s = 0.f, q = 0.f;
+        for (int k = 0; k < nslab; ++k) {
+            const float* o = part + (((long)r * nslab + k) * G + threadIdx.x) * 2;
+            s += o[0]; q += o[1];
+        }
+        const float n = (float)HW * (float)cpg;
+        const float mean = s / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        gmean[threadIdx.x] = mean;
+        grstd[threadIdx.x] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int gi = c / cpg;
+        const float a = grstd[gi] * (float)gamma[c];
+        sa[c] = a;
+        sb[c] = (float)beta[c] - gmean[gi] * a;
+    }
+    __syncthreads();
+    const int nchunk = C >> 3;
+    const int p0 = blockIdx.x * pix_per_blk;
+    const int p1 = min(HW, p0 + pix_per_blk);
+    const long total = (long)(p1 - p0) * nchunk;
+    const f16* xb = X + (long)r * HW * ldx;
+    f16* yb = Y + (long)r * HW * ldy;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int p = p0 + (int)(i / nchunk), ch = (int)(i % nchunk);
+        const f16x8 v = *(const f16x8*)(xb + (long)p * ldx + ch * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] * sa[ch * 8 + j] + sb[ch * 8 + j];
+            if (silu) f = silu_f(f);
+            o[j] = (f16)f;
+        }
+        *(f16x8*)(yb + (long)p * ldy + ch * 8) = o;
+    }
+}
+
+// ---- LayerNorm: one wave per row, row kept in registers (C <= 2560) -------------------------------
+// y = LN(x) * gamma + beta                      (gamma/beta optional)
+// y = y * (1 + scale[row / rows_per_mod]) + shift[row / rows_per_mod]   (optional adaLN modulation)
+// transposed != 0 writes y^T: Y[c][col_off(row)] with col = (row / tr_rows) * tr_bstride + row % tr_rows.
+__global__ __launch_bounds__(256) void ln_kernel(const f16* X, long ldx, f16* Y, long ldy, int rows, int C, const f16* gamma,
+                                                 const f16* beta, float eps, const f16* shift, const f16* scale, long ldmod,
+                                                 int rows_per_mod, int transposed, int tr_rows, long tr_bstride) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C >> 3;
+    constexpr int MAXK = GN_MAXC / 8 / 64;   // 5 chunks per lane
+    f16x8 v[MAXK];
+    float s = 0.f;
+    const f16* x = X + (long)row * ldx;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < nchunk) {
+            v[k] = *(const f16x8*)(x + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[k][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)v[k][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const f16* sh = shift ? shift + (long)(row / rows_per_mod) * ldmod : nullptr;
+    const f16* sc = scale ? scale + (long)(row / rows_per_mod) * ldmod : nullptr;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < nchunk) {
+            f16x8 o;
+            f16x8 gm, bt, s8, c8;
+            if (gamma) gm = *(const f16x8*)(gamma + ch * 8);
+            if (beta) bt = *(const f16x8*)(beta + ch * 8);
+            if (sh) { s8 = *(const f16x8*)(sh + ch * 8); c8 = *(const f16x8*)(sc + ch * 8); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = ((float)v[k][j] - mean) * rstd;
+                if (gamma) f *= (float)gm[j];
+                if (beta) f += (float)bt[j];
+                if (sh) f = f * (1.0f + (float)c8[j]) + (float)s8[j];
+                o[j] = (f16)f;
+            }
+            if (!transposed) {
+                *(f16x8*)(Y + (long)row * ldy + ch * 8) = o;
+            } else {
+                const long col = (long)(row / tr_rows) * tr_bstride + (row % tr_rows);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Y[(long)(ch * 8 + j) * ldy + col] = o[j];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
+                                      int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!X || !Y || !gamma || !beta || !workspace) return IIR_EINVAL;
+    if (C % 8 || C > GN_MAXC || groups <= 0 || groups > 64 || C % groups || ldx % 8 || ldy % 8) return IIR_EINVAL;
+    if (R <= 0 || HW <= 0) return IIR_EINVAL;
+    // slabs: enough blocks to fill the chip, at least 64 pixels each
+    int nslab = (HW + 63) / 64;
+    const int want = (2048 + R - 1) / R;
+    if (nslab > want) nslab = want;
+    if (nslab > 256) nslab = 256;
+    if (nslab < 1) nslab = 1;
+    const int pps = (HW + nslab - 1) / nslab;
+    nslab = (HW + pps - 1) / pps;
+    if ((int64_t)R * nslab * groups * 2 * 4 > workspace_bytes) return IIR_EINVAL;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, R), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, HW, C,
+                       groups, pps, (float*)workspace);
+    // apply: ~16K elements per block
+    int ppb = 16384 / C; if (ppb < 1) ppb = 1;
+    const int nblk = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, R), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, (f16*)Y,
+                       (long)ldy, HW, C, groups, ppb, (const float*)workspace, nslab, (const f16*)gamma, (const f16*)beta, eps,
+                       silu);
+    return iir_launch_status();
+}
+
+extern "C" int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups) { return (int64_t)R * 256 * groups * 2 * 4; }
+
+extern "C" int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t rows, int32_t C, const void* gamma,
+                                 const void* beta, float eps, const void* shift, const void* scale, int64_t ldmod,
+                                 int32_t rows_per_mod, int32_t transposed, int32_t tr_rows, int64_t tr_bstride, void* stream) {
+    if (!X || !Y || rows <= 0 || C % 8 || C > GN_MAXC || ldx % 8) return IIR_EINVAL;
+    if ((shift == nullptr) != (scale == nullptr)) return IIR_EINVAL;
+    if (shift && (rows_per_mod <= 0 || ldmod % 8)) return IIR_EINVAL;
+    if (!transposed && ldy % 8) return IIR_EINVAL;
+    if (transposed && tr_rows <= 0) return IIR_EINVAL;
+    hipLaunchKernelGGL(ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, (f16*)Y,
+                       (long)ldy, rows, C, (const f16*)gamma, (const f16*)beta, eps, (const f16*)shift, (const f16*)scale,
+                       (long)ldmod, rows_per_mod, transposed, tr_rows, (long)tr_bstride);
+    return iir_launch_status();
+}

@@ -1,0 +1,220 @@
+// K9 and layout glue: timestep sinusoid, SiLU, concat/copy with scaled add, latent pack/unpack,
+// classifier-free guidance + scheduler update, LCM one-step preview.  All HBM-bound pointwise work.
+// Compiled with -ffp-contract=off: the scheduler arithmetic follows the reference's fp32 op order
+// (no FMA contraction) so it can be compared with the CPU restatement at rounding level.
+//
+// Replaces: Timesteps (module/min_sdxl.py:205-224); nn.SiLU on temb (:263); torch.cat of skip tensors
+// (:712) with the ControlNet residual add folded in (pipelines/sdxl_instantir.py:1602-1603 and diffusers'
+// `skip + residual`); latent_model_input = cat([latents]*2) (:1503); CFG (:1619-1621); main scheduler
+// step (:1629-1633, DDPM / DDIM linear forms); LCMSingleStepScheduler.step
+// (schedulers/lcm_single_step_scheduler.py:455-484).
+#include "common.h"
+#include "../../include/instantir_hip.h"
+
+namespace {
+
+__global__ void sinusoid_kernel(const float* vals, int n_vals, int rows, int dim, f16* out, long ldo, int col_off) {
+    // out[row][col_off + v*dim + (0..dim)] = [cos(val_v * w_k) | sin(val_v * w_k)], w_k = exp(-ln(1e4) k / (dim/2))
+    // vals is [rows][n_vals] when rows_vals (vals per row), broadcast when n_vals rows == 1 handled by host.
+    const int half = dim >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = rows * n_vals * half;
+    if (idx >= total) return;
+    const int k = idx % half;
+    const int v = (idx / half) % n_vals;
+    const int r = idx / (half * n_vals);
+    const float w = expf(-9.210340371976184f * (float)k / (float)half);
+    const float a = vals[r * n_vals + v] * w;
+    f16* o = out + (long)r * ldo + col_off + v * dim;
+    o[k] = (f16)cosf(a);
+    o[half + k] = (f16)sinf(a);
+}
+
+__global__ void silu_kernel(const f16* x, f16* y, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const f16x8 v = *(const f16x8*)(x + i * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)silu_f((float)v[j]);
+    *(f16x8*)(y + i * 8) = o;
+}
+
+// dst[m][dst_off + c] = src[m][c] + add[m][c] * add_scale[m / rows_per_scale]   (add optional)
+__global__ void copy_add_kernel(const f16* src, long lds_, f16* dst, long ldd, long dst_off, long M, int C, const f16* add,
+                                long lda, const float* add_scale, int rows_per_scale) {
+    const int nchunk = C >> 3;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * nchunk) return;
+    const long m = i / nchunk;
+    const int ch = (int)(i % nchunk);
+    f16x8 v = *(const f16x8*)(src + m * lds_ + ch * 8);
+    if (add) {
+        const f16x8 a = *(const f16x8*)(add + m * lda + ch * 8);
+        const float s = add_scale ? add_scale[m / rows_per_scale] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (f16)((float)v[j] + (float)a[j] * s);
+    }
+    *(f16x8*)(dst + m * ldd + dst_off + ch * 8) = v;
+}
+
+// fp32 NCHW (B, C, H, W) -> f16 NHWC rows (rep*B, H*W, ldo), channels [0,C) written, repeated `rep` times
+__global__ void pack_latent_kernel(const float* x, int B, int C, int HW, f16* out, long ldo, int rep, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < C; ++c) {
+        const f16 v = (f16)(x[((long)b * C + c) * HW + p] * scale);
+        for (int k = 0; k < rep; ++k) out[((long)(k * B + b) * HW + p) * ldo + c] = v;
+    }
+}
+
+// f16 NHWC rows (R, H*W, ldi) channels [0,C) -> fp32 NCHW (R, C, H, W)
+__global__ void unpack_latent_kernel(const f16* in, long ldi, int R, int C, int HW, float* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)R * HW) return;
+    const int r = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < C; ++c) out[((long)r * C + c) * HW + p] = (float)in[((long)r * HW + p) * ldi + c];
+}
+
+// Main scheduler step with classifier-free guidance, fp32.
+//   eps  = cfg ? u + g * (c - u) : c         (u = rows [0,B), c = rows [B,2B) of the UNet output)
+//   x0   = (x - sqrt_beta_t * eps) / sqrt_alpha_t
+//   prev = k_x0 * x0 + k_x * x + k_eps * eps + k_noise * noise
+// coef (device, fp32[8]) = {g, sqrt_beta_t, sqrt_alpha_t, k_x0, k_x, k_eps, k_noise, unused}
+__global__ void sched_step_kernel(const f16* eps_nhwc, long lde, int B, int C, int HW, int cfg, const float* coef,
+                                  const float* x, const float* noise, float* prev, float* x0_out, float* eps_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i % HW);
+    const float g = coef[0], sb = coef[1], sa = coef[2], k0 = coef[3], k1 = coef[4], k2 = coef[5], k3 = coef[6];
+    for (int c = 0; c < C; ++c) {
+        const long o = ((long)b * C + c) * HW + p;
+        float e;
+        if (cfg) {
+            // the reference forms the guidance in the UNet dtype (fp16) -- keep fp32 here (>= precision)
+            const float u = (float)eps_nhwc[((long)b * HW + p) * lde + c];
+            const float t = (float)eps_nhwc[((long)(B + b) * HW + p) * lde + c];
+            e = u + g * (t - u);
+        } else {
+            e = (float)eps_nhwc[((long)b * HW + p) * lde + c];
+        }
+        const float xv = x[o];
+        const float x0 = (xv - sb * e) / sa;
+        float pv = k0 * x0 + k1 * xv;
+        if (k2 != 0.f) pv = pv + k2 * e;
+        if (noise && k3 != 0.f) pv = pv + k3 * noise[o];
+        prev[o] = pv;
+        if (x0_out) x0_out[o] = x0;
+        if (eps_out) eps_out[o] = e;
+    }
+}
+
+// LCM one-step preview for every row of the CFG-doubled batch:
+//   x0 = (x - sqrt_beta * eps) / sqrt_alpha ; den = c_out * x0 + c_skip * x
+// coef (device fp32[4]) = {sqrt_beta, sqrt_alpha, c_out, c_skip}; x is the fp32 latent (B rows, shared by
+// both CFG halves), eps the UNet output (R = rep*B rows, NHWC f16).  Writes f16 NHWC (R rows) and
+// optionally fp32 NCHW (R rows).
+__global__ void lcm_step_kernel(const f16* eps_nhwc, long lde, int B, int rep, int C, int HW, const float* coef,
+                                const float* x, f16* out_nhwc, long ldo, float* out_nchw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * rep * HW) return;
+    const int r = (int)(i / HW), p = (int)(i % HW);
+    const int b = r % B;
+    const float sb = coef[0], sa = coef[1], co = coef[2], cs = coef[3];
+    for (int c = 0; c < C; ++c) {
+        const float xv = x[((long)b * C + c) * HW + p];
+        const float e = (float)eps_nhwc[((long)r * HW + p) * lde + c];
+        const float x0 = (xv - sb * e) / sa;
+        const float d = co * x0 + cs * xv;
+        out_nhwc[((long)r * HW + p) * ldo + c] = (f16)d;
+        if (out_nchw) out_nchw[((long)r * C + c) * HW + p] = d;
+    }
+}
+
+// out[cols][rows_pad] = in[rows][cols]^T with zero fill of the row padding (one-time V^T builds)
+__global__ void transpose_kernel(const f16* in, long ldi, int rows, int cols, f16* out, long ldo, int rows_pad) {
+    __shared__ f16 tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx over cols, by over rows
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * ldi + c] : (f16)0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (c < cols && r < rows_pad) out[(long)c * ldo + r] = tile[threadIdx.x][j];
+    }
+}
+
+inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
+
+}  // namespace
+
+extern "C" int iir_sinusoid_f16(const float* vals, int32_t n_vals, int32_t rows, int32_t dim, void* out, int64_t ldo,
+                                int32_t col_off, void* stream) {
+    if (!vals || !out || n_vals <= 0 || rows <= 0 || dim <= 0 || dim % 2) return IIR_EINVAL;
+    const int total = rows * n_vals * (dim / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, vals, n_vals, rows, dim,
+                       (f16*)out, (long)ldo, col_off);
+    return iir_launch_status();
+}
+
+extern "C" int iir_silu_f16(const void* x, void* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0 || n % 8) return IIR_EINVAL;
+    hipLaunchKernelGGL(silu_kernel, dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, n / 8);
+    return iir_launch_status();
+}
+
+extern "C" int iir_copy_add_f16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t dst_off, int64_t M, int32_t C,
+                                const void* add, int64_t lda, const float* add_scale, int32_t rows_per_scale, void* stream) {
+    if (!src || !dst || M <= 0 || C <= 0 || C % 8 || lds % 8 || ldd % 8 || dst_off % 8) return IIR_EINVAL;
+    if (add && (lda % 8)) return IIR_EINVAL;
+    if (add_scale && rows_per_scale <= 0) return IIR_EINVAL;
+    hipLaunchKernelGGL(copy_add_kernel, dim3(nblk(M * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)src,
+                       (long)lds, (f16*)dst, (long)ldd, (long)dst_off, (long)M, C, (const f16*)add, (long)lda, add_scale,
+                       rows_per_scale);
+    return iir_launch_status();
+}
+
+extern "C" int iir_pack_latent(const float* x, int32_t B, int32_t C, int32_t HW, void* out, int64_t ldo, int32_t rep,
+                               float scale, void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || HW <= 0 || rep <= 0 || ldo < C) return IIR_EINVAL;
+    hipLaunchKernelGGL(pack_latent_kernel, dim3(nblk((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, B, C, HW,
+                       (f16*)out, (long)ldo, rep, scale);
+    return iir_launch_status();
+}
+
+extern "C" int iir_unpack_latent(const void* in, int64_t ldi, int32_t R, int32_t C, int32_t HW, float* out, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0 || HW <= 0 || ldi < C) return IIR_EINVAL;
+    hipLaunchKernelGGL(unpack_latent_kernel, dim3(nblk((long)R * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)in,
+                       (long)ldi, R, C, HW, out);
+    return iir_launch_status();
+}
+
+extern "C" int iir_sched_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int32_t HW, int32_t cfg,
+                              const float* coef, const float* x, const float* noise, float* prev, float* x0_out,
+                              float* eps_out, void* stream) {
+    if (!eps_nhwc || !coef || !x || !prev || B <= 0 || C <= 0 || HW <= 0 || lde < C) return IIR_EINVAL;
+    hipLaunchKernelGGL(sched_step_kernel, dim3(nblk((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)eps_nhwc, (long)lde, B, C, HW, cfg, coef, x, noise, prev, x0_out, eps_out);
+    return iir_launch_status();
+}
+
+extern "C" int iir_lcm_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t rep, int32_t C, int32_t HW,
+                            const float* coef, const float* x, void* out_nhwc, int64_t ldo, float* out_nchw, void* stream) {
+    if (!eps_nhwc || !coef || !x || !out_nhwc || B <= 0 || rep <= 0 || C <= 0 || HW <= 0 || lde < C || ldo < C) return IIR_EINVAL;
+    hipLaunchKernelGGL(lcm_step_kernel, dim3(nblk((long)B * rep * HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)eps_nhwc, (long)lde, B, rep, C, HW, coef, x, (f16*)out_nhwc, (long)ldo, out_nchw);
+    return iir_launch_status();
+}
+
+extern "C" int iir_transpose_f16(const void* in, int64_t ldi, int32_t rows, int32_t cols, void* out, int64_t ldo,
+                                 int32_t rows_pad, void* stream) {
+    if (!in || !out || rows <= 0 || cols <= 0 || rows_pad < rows || ldo < rows_pad) return IIR_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows_pad + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream,
+                       (const f16*)in, (long)ldi, rows, cols, (f16*)out, (long)ldo, rows_pad);
+    return iir_launch_status();
+}
+
+extern "C" int iir_abi_version(void) { return IIR_ABI_VERSION; }

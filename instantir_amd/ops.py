@@ -1,0 +1,210 @@
+"""Thin launch wrappers: torch CUDA tensors in, one C-ABI call out.  torch is used for device
+memory and the current stream only; no arithmetic happens here.
+
+All activations are fp16, channel/feature dimension contiguous.  Matrices are 2-D views whose
+row stride may exceed the width (column slices of wider buffers are passed as views).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_SFT  # noqa: F401
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t, name):
+    if t.dtype != torch.float16 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a 2-D fp16 CUDA tensor with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+
+
+_zero_pages = {}
+
+
+def zero_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.float16, device=device)
+        _zero_pages[device] = z
+    return z
+
+
+def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
+         tile=0):
+    """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues)."""
+    _chk2d(a, "a"); _chk2d(w, "w"); _chk2d(out, "out")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous():
+        raise ValueError("w must be contiguous (N,K) with K matching a")
+    n_out = N if epi == EPI_PLAIN else N // 2
+    if out.shape != (M, n_out):
+        raise ValueError(f"out shape {tuple(out.shape)} != {(M, n_out)}")
+    d = L.GemmDesc()
+    d.A, d.lda = a.data_ptr(), a.stride(0)
+    d.W = w.data_ptr()
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.bias = _p(bias)
+    if rowbias is not None:
+        _chk2d(rowbias, "rowbias")
+        d.rowbias, d.ldrb, d.rows_per_rb = rowbias.data_ptr(), rowbias.stride(0), rows_per_rb
+    if res is not None:
+        _chk2d(res, "res")
+        d.res, d.ldr = res.data_ptr(), res.stride(0)
+    d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
+    L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
+    return out
+
+
+def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None, rows_per_rb=1, res=None,
+           epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0, tile=0):
+    """x (R,H,W,Cin) NHWC view (pixel stride x.stride(2)), w (Cout,k,k,Cin) contiguous, out (R*Ho*Wo, Cout[/2]) 2-D view."""
+    R, H, Wd, Cin = x.shape
+    if x.dtype != torch.float16 or x.stride(3) != 1 or x.stride(1) != Wd * x.stride(2) or x.stride(0) != H * Wd * x.stride(2):
+        raise ValueError("x must be a dense NHWC fp16 view (only the pixel stride may exceed Cin)")
+    _chk2d(out, "out")
+    Cout = w.shape[0]
+    if tuple(w.shape[1:]) != (ksize, ksize, Cin) or not w.is_contiguous():
+        raise ValueError("w must be contiguous (Cout,k,k,Cin)")
+    d = L.ConvDesc()
+    d.X, d.ldx = x.data_ptr(), x.stride(2)
+    d.R, d.H, d.Wd, d.Cin = R, H, Wd, Cin
+    d.Wt = w.data_ptr()
+    d.Y, d.ldy = out.data_ptr(), out.stride(0)
+    d.Cout, d.ksize, d.stride, d.upsample = Cout, ksize, stride, int(bool(upsample))
+    d.bias = _p(bias)
+    if rowbias is not None:
+        _chk2d(rowbias, "rowbias")
+        d.rowbias, d.ldrb, d.rows_per_rb = rowbias.data_ptr(), rowbias.stride(0), rows_per_rb
+    if res is not None:
+        _chk2d(res, "res")
+        d.res, d.ldr = res.data_ptr(), res.stride(0)
+    d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
+    d.zero_page = zero_page(x.device).data_ptr()
+    L.check(L.load().iir_conv2d_nhwc_f16(C.byref(d), _stream()), "iir_conv2d_nhwc_f16")
+    return out
+
+
+def attention(q, o, kv, batch, heads, Tq, scale=0.125):
+    """q, o: 2-D views (batch*Tq, heads*64).  kv: list of 1-2 tuples (k2d, k_batch_rows, vt2d, vt_batch_stride, Tkv):
+    k2d (batch*k_batch_rows, heads*64) view, vt2d (heads*64, cols) view with batch b starting at column b*vt_batch_stride."""
+    _chk2d(q, "q"); _chk2d(o, "o")
+    d = L.AttnDesc()
+    d.Q, d.ldq, d.q_batch_stride = q.data_ptr(), q.stride(0), Tq * q.stride(0)
+    d.O, d.ldo, d.o_batch_stride = o.data_ptr(), o.stride(0), Tq * o.stride(0)
+    d.batch, d.heads, d.Tq, d.nseg, d.scale = batch, heads, Tq, len(kv), scale
+    for i, (k, k_rows, vt, vbs, tkv) in enumerate(kv):
+        _chk2d(k, "k"); _chk2d(vt, "vt")
+        d.kv[i].K, d.kv[i].ldk, d.kv[i].k_batch_stride = k.data_ptr(), k.stride(0), k_rows * k.stride(0)
+        d.kv[i].Vt, d.kv[i].ldvt, d.kv[i].vt_batch_stride = vt.data_ptr(), vt.stride(0), vbs
+        d.kv[i].Tkv = tkv
+    L.check(L.load().iir_attention_d64_f16(C.byref(d), _stream()), "iir_attention_d64_f16")
+    return o
+
+
+_gn_ws = {}
+
+
+def _gn_workspace(device, R, groups):
+    need = L.load().iir_groupnorm_workspace_bytes(R, groups)
+    ws = _gn_ws.get(device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=device)
+        _gn_ws[device] = ws
+    return ws
+
+
+def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32):
+    """x, out: 2-D views (R*HW, C)."""
+    _chk2d(x, "x"); _chk2d(out, "out")
+    Cc = x.shape[1]
+    ws = _gn_workspace(x.device, R, groups)
+    L.check(L.load().iir_groupnorm_nhwc_f16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, HW, Cc, groups,
+                                            gamma.data_ptr(), beta.data_ptr(), eps, int(silu), ws.data_ptr(),
+                                            ws.numel() * 4, _stream()), "iir_groupnorm_nhwc_f16")
+    return out
+
+
+def layernorm(x, out, gamma=None, beta=None, eps=1e-5, shift=None, scale=None, rows_per_mod=1, transposed=False,
+              tr_rows=1, tr_bstride=0):
+    _chk2d(x, "x"); _chk2d(out, "out")
+    rows, Cc = x.shape
+    ldmod = shift.stride(0) if shift is not None else 0
+    L.check(L.load().iir_layernorm_f16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, Cc, _p(gamma),
+                                       _p(beta), eps, _p(shift), _p(scale), ldmod, rows_per_mod, int(transposed), tr_rows,
+                                       tr_bstride, _stream()), "iir_layernorm_f16")
+    return out
+
+
+def sinusoid(vals, out, dim, col_off=0):
+    """vals fp32 (rows, n_vals) device tensor; out 2-D fp16 view."""
+    rows, n_vals = vals.shape
+    L.check(L.load().iir_sinusoid_f16(vals.data_ptr(), n_vals, rows, dim, out.data_ptr(), out.stride(0), col_off,
+                                      _stream()), "iir_sinusoid_f16")
+    return out
+
+
+def silu(x, out):
+    L.check(L.load().iir_silu_f16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "iir_silu_f16")
+    return out
+
+
+def copy_add(src, dst, dst_off=0, add=None, add_scale=None, rows_per_scale=1):
+    """dst[:, dst_off:dst_off+C] = src + add * add_scale[row // rows_per_scale]."""
+    _chk2d(src, "src"); _chk2d(dst, "dst")
+    M, Cc = src.shape
+    L.check(L.load().iir_copy_add_f16(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), dst_off, M, Cc,
+                                      _p(add), add.stride(0) if add is not None else 0, _p(add_scale), rows_per_scale,
+                                      _stream()), "iir_copy_add_f16")
+    return dst
+
+
+def pack_latent(x, out, rep=1, scale=1.0):
+    """x fp32 (B,C,H,W) contiguous -> out 2-D fp16 view (rep*B*H*W, ld>=C)."""
+    B, Cc, H, Wd = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    L.check(L.load().iir_pack_latent(x.data_ptr(), B, Cc, H * Wd, out.data_ptr(), out.stride(0), rep, scale, _stream()),
+            "iir_pack_latent")
+    return out
+
+
+def unpack_latent(x2d, out):
+    """x2d fp16 view (R*H*W, ld) -> out fp32 (R,C,H,W)."""
+    R, Cc, H, Wd = out.shape
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    L.check(L.load().iir_unpack_latent(x2d.data_ptr(), x2d.stride(0), R, Cc, H * Wd, out.data_ptr(), _stream()),
+            "iir_unpack_latent")
+    return out
+
+
+def sched_step(eps2d, B, coef, x, prev, noise=None, cfg=True, x0_out=None, eps_out=None):
+    _, Cc, H, Wd = x.shape
+    L.check(L.load().iir_sched_step(eps2d.data_ptr(), eps2d.stride(0), B, Cc, H * Wd, int(cfg), coef.data_ptr(),
+                                    x.data_ptr(), _p(noise), prev.data_ptr(), _p(x0_out), _p(eps_out), _stream()),
+            "iir_sched_step")
+    return prev
+
+
+def lcm_step(eps2d, B, rep, coef, x, out2d, out_nchw=None):
+    _, Cc, H, Wd = x.shape
+    L.check(L.load().iir_lcm_step(eps2d.data_ptr(), eps2d.stride(0), B, rep, Cc, H * Wd, coef.data_ptr(), x.data_ptr(),
+                                  out2d.data_ptr(), out2d.stride(0), _p(out_nchw), _stream()), "iir_lcm_step")
+    return out2d
+
+
+def transpose(x, out, rows_pad):
+    _chk2d(x, "x"); _chk2d(out, "out")
+    rows, cols = x.shape
+    L.check(L.load().iir_transpose_f16(x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), out.stride(0), rows_pad,
+                                       _stream()), "iir_transpose_f16")
+    return out

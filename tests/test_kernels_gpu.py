@@ -1,0 +1,288 @@
+"""GPU: every HIP kernel, through the C ABI, against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from instantir_amd import lib
+    lib.load()          # fails loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+def _close(got, want, rtol=2e-3, atol=2e-3, what=""):
+    got = got.float().cpu()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{want.numel()} off, max err {err.max().item():.4g} (ref max {want.abs().max().item():.4g})"
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 132, 64), (2, 320, 320), (1000, 640, 1280)])
+def test_gemm_plain(dev, tile, M, N, K):
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a, w = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5)
+    bias, res = _rand(g, N), _rand(g, M, N)
+    rb = _rand(g, (M + 3) // 4, N)
+    want = F.silu(a.float() @ w.float().T + bias.float() + rb.float().repeat_interleave(4, 0)[:M]) + res.float()
+    out = torch.zeros(M, N + 8, dtype=torch.half, device=dev)      # wider buffer: exercises ldc
+    ops.gemm(a.to(dev), w.to(dev), out[:, :N], bias=bias.to(dev), rowbias=rb.to(dev), rows_per_rb=4, res=res.to(dev),
+             act=ops.ACT_SILU, tile=tile)
+    torch.cuda.synchronize()
+    _close(out[:, :N], want, what="gemm")
+    assert out[:, N:].abs().max().item() == 0          # nothing written outside the view
+
+
+def test_gemm_strided_a_and_scale(dev):
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(3)
+    big = _rand(g, 200, 256)
+    a = big[:, 64:192]                                   # column slice: lda 256, K 128
+    w = _rand(g, 64, 128, scale=0.1)
+    out = torch.empty(200, 64, dtype=torch.half, device=dev)
+    bigd = big.to(dev)
+    ops.gemm(bigd[:, 64:192], w.to(dev), out, out_scale=0.5)
+    torch.cuda.synchronize()
+    _close(out, 0.5 * (a.float() @ w.float().T), what="gemm strided")
+
+
+@pytest.mark.parametrize("M,n_out,K", [(256, 128, 64), (130, 48, 128), (64, 2560, 640)])
+def test_gemm_geglu(dev, M, n_out, K):
+    from instantir_amd import ops
+    from instantir_amd.packing import pair_rows
+    g = torch.Generator().manual_seed(n_out)
+    a, w, b = _rand(g, M, K), _rand(g, 2 * n_out, K, scale=K ** -0.5), _rand(g, 2 * n_out)
+    h = a.float() @ w.float().T + b.float()
+    want = h[:, :n_out] * F.gelu(h[:, n_out:])
+    wp = pair_rows(w[:n_out], w[n_out:]).to(dev)
+    bp = pair_rows(b[:n_out], b[n_out:]).to(dev)
+    out = torch.empty(M, n_out, dtype=torch.half, device=dev)
+    ops.gemm(a.to(dev), wp, out, bias=bp, epi=ops.EPI_GEGLU)
+    torch.cuda.synchronize()
+    _close(out, want, what="geglu")
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("R,H,W,Cin,Cout,stride,ups", [
+    (2, 16, 16, 64, 64, 1, False), (1, 9, 7, 128, 96, 1, False), (2, 16, 16, 64, 128, 2, False),
+    (2, 8, 8, 64, 64, 1, True), (1, 32, 16, 320, 320, 1, False)])
+def test_conv3x3(dev, R, H, W, Cin, Cout, stride, ups):
+    from instantir_amd import ops
+    from instantir_amd.packing import conv_weight_nhwc
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x, w, b = _rand(g, R, Cin, H, W), _rand(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5), _rand(g, Cout)
+    temb = _rand(g, R, Cout)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    want = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=1) + temb.float()[:, :, None, None]
+    Ho, Wo = want.shape[2:]
+    res = _rand(g, R, Cout, Ho, Wo)
+    want = _nhwc(want + res.float()).reshape(R * Ho * Wo, Cout)
+    xd = torch.zeros(R, H, W, Cin + 64, dtype=torch.half, device=dev)       # pixel stride > Cin
+    xd[..., :Cin] = _nhwc(x).to(dev)
+    out = torch.empty(R * Ho * Wo, Cout, dtype=torch.half, device=dev)
+    ops.conv2d(xd[..., :Cin], conv_weight_nhwc(w).to(dev), out, ksize=3, stride=stride, upsample=ups, bias=b.to(dev),
+               rowbias=temb.to(dev), rows_per_rb=Ho * Wo, res=_nhwc(res).reshape(-1, Cout).to(dev))
+    torch.cuda.synchronize()
+    _close(out, want, what="conv3x3")
+
+
+def test_conv_padded_input_channels_and_1x1(dev):
+    from instantir_amd import ops
+    from instantir_amd.packing import conv_weight_nhwc
+    g = torch.Generator().manual_seed(5)
+    x, w, b = _rand(g, 2, 4, 16, 16), _rand(g, 64, 4, 3, 3, scale=1 / 6), _rand(g, 64)
+    want = _nhwc(F.conv2d(x.float(), w.float(), b.float(), padding=1)).reshape(-1, 64)
+    xd = torch.zeros(2, 16, 16, 64, dtype=torch.half, device=dev)
+    xd[..., :4] = _nhwc(x).to(dev)
+    out = torch.empty(2 * 256, 64, dtype=torch.half, device=dev)
+    ops.conv2d(xd, conv_weight_nhwc(w, 64).to(dev), out, bias=b.to(dev))
+    torch.cuda.synchronize()
+    _close(out, want, what="conv_in")
+    w1 = _rand(g, 128, 64, 1, 1, scale=1 / 8)
+    y = torch.empty(512, 128, dtype=torch.half, device=dev)
+    ops.conv2d(out.view(2, 16, 16, 64), conv_weight_nhwc(w1).to(dev), y, ksize=1)
+    torch.cuda.synchronize()
+    _close(y, out.float().cpu() @ w1.float().reshape(128, 64).T, what="conv1x1")
+
+
+def test_conv_sft_epilogue(dev):
+    """module/aggregator.py:76-86: h * (mul(actv) + 1) + add(actv) with the two convs fused."""
+    from instantir_amd import ops
+    from instantir_amd.packing import conv_weight_nhwc, pair_rows
+    g = torch.Generator().manual_seed(9)
+    R, H, W, Ch, C = 2, 8, 8, 64, 96
+    actv, h = _rand(g, R, Ch, H, W), _rand(g, R, C, H, W)
+    wm, wa = _rand(g, C, Ch, 3, 3, scale=1 / 24), _rand(g, C, Ch, 3, 3, scale=1 / 24)
+    bm, ba = _rand(g, C), _rand(g, C)
+    gamma = F.conv2d(actv.float(), wm.float(), bm.float(), padding=1)
+    beta = F.conv2d(actv.float(), wa.float(), ba.float(), padding=1)
+    want = _nhwc(h.float() * (gamma + 1) + beta).reshape(-1, C)
+    wp = pair_rows(conv_weight_nhwc(wm), conv_weight_nhwc(wa)).to(dev)
+    bp = pair_rows(bm, ba).to(dev)
+    out = torch.empty(R * H * W, C, dtype=torch.half, device=dev)
+    ops.conv2d(_nhwc(actv).to(dev), wp, out, bias=bp, res=_nhwc(h).reshape(-1, C).to(dev), epi=ops.EPI_SFT)
+    torch.cuda.synchronize()
+    _close(out, want, what="sft")
+
+
+def _sdpa_ref(q, k, v, heads):
+    b, t, c = q.shape
+    sp = lambda x: x.float().reshape(b, -1, heads, 64).transpose(1, 2)
+    o = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / 8.0, dim=-1) @ sp(v)
+    return o.transpose(1, 2).reshape(b, t, c)
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tkv", [(2, 2, 256, 256), (1, 3, 200, 200), (2, 1, 50, 136), (1, 2, 16, 16)])
+def test_self_attention(dev, B, heads, Tq, Tkv):
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(Tq + heads)
+    C = heads * 64
+    q, k, v = _rand(g, B, Tq, C), _rand(g, B, Tkv, C), _rand(g, B, Tkv, C)
+    want = _sdpa_ref(q, k, v, heads).reshape(B * Tq, C)
+    # q, k live as column slices of one fused buffer (like the QKV GEMM output)
+    qk = torch.zeros(B * max(Tq, Tkv), 2 * C, dtype=torch.half, device=dev)
+    qd = torch.empty(B * Tq, C, dtype=torch.half, device=dev); qd.copy_(q.reshape(-1, C))
+    kbuf = torch.zeros(B * Tkv, 2 * C, dtype=torch.half, device=dev)
+    kbuf[:, C:] = k.reshape(-1, C).to(dev)
+    tpad = (Tkv + 7) // 8 * 8
+    vt = torch.zeros(C, B * tpad, dtype=torch.half, device=dev)
+    for b in range(B):
+        vt[:, b * tpad:b * tpad + Tkv] = v[b].T.to(dev)
+    o = torch.empty(B * Tq, C, dtype=torch.half, device=dev)
+    ops.attention(qd, o, [(kbuf[:, C:], Tkv, vt, tpad, Tkv)], B, heads, Tq)
+    torch.cuda.synchronize()
+    _close(o, want, rtol=3e-3, atol=3e-3, what="self-attn")
+
+
+def test_two_segment_attention(dev):
+    """text KV (13 keys) + IP KV (16 keys) sharing one query, outputs summed
+    (module/ip_adapter/attention_processor.py:1165,1185,1192)."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, heads, Tq = 2, 2, 100
+    C = heads * 64
+    q = _rand(g, B, Tq, C)
+    k1, v1, k2, v2 = _rand(g, B, 13, C), _rand(g, B, 13, C), _rand(g, B, 16, C), _rand(g, B, 16, C)
+    want = (_sdpa_ref(q, k1, v1, heads) + _sdpa_ref(q, k2, v2, heads)).reshape(B * Tq, C)
+
+    def vt_of(v, T):
+        tp = (T + 7) // 8 * 8
+        out = torch.zeros(C, B * tp, dtype=torch.half, device=dev)
+        for b in range(B):
+            out[:, b * tp:b * tp + T] = v[b].T.to(dev)
+        return out, tp
+
+    vt1, tp1 = vt_of(v1, 13)
+    vt2, tp2 = vt_of(v2, 16)
+    o = torch.empty(B * Tq, C, dtype=torch.half, device=dev)
+    ops.attention(q.reshape(-1, C).to(dev), o,
+                  [(k1.reshape(-1, C).to(dev), 13, vt1, tp1, 13), (k2.reshape(-1, C).to(dev), 16, vt2, tp2, 16)],
+                  B, heads, Tq)
+    torch.cuda.synchronize()
+    _close(o, want, rtol=3e-3, atol=3e-3, what="2-seg attn")
+
+
+def test_attention_online_softmax_rescale(dev):
+    """Force the running-max update late: one key far above the rest sits in the last tile."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, heads, T = 1, 1, 256
+    q, k, v = _rand(g, B, T, 64), _rand(g, B, T, 64), _rand(g, B, T, 64)
+    k[0, 250] = q[0, 3] * 4.0
+    want = _sdpa_ref(q, k, v, heads).reshape(T, 64)
+    vt = v[0].T.contiguous().to(dev)
+    o = torch.empty(T, 64, dtype=torch.half, device=dev)
+    ops.attention(q.reshape(-1, 64).to(dev), o, [(k.reshape(-1, 64).to(dev), T, vt, T, T)], B, heads, T)
+    torch.cuda.synchronize()
+    _close(o, want, rtol=3e-3, atol=3e-3, what="attn rescale")
+
+
+@pytest.mark.parametrize("R,HW,C,silu,eps", [(2, 256, 64, True, 1e-5), (2, 1024, 320, True, 1e-5), (1, 64, 2560, False, 1e-6),
+                                              (3, 100, 960, True, 1e-5)])
+def test_groupnorm(dev, R, HW, C, silu, eps):
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = _rand(g, R, HW, C) + 0.5
+    gm, bt = _rand(g, C) + 1, _rand(g, C)
+    want = F.group_norm(x.float().permute(0, 2, 1), 32, gm.float(), bt.float(), eps).permute(0, 2, 1)
+    if silu:
+        want = F.silu(want)
+    xd = torch.zeros(R * HW, C + 64, dtype=torch.half, device=dev)
+    xd[:, :C] = x.reshape(-1, C).to(dev)
+    out = torch.empty(R * HW, C, dtype=torch.half, device=dev)
+    ops.groupnorm(xd[:, :C], out, R, HW, gm.to(dev), bt.to(dev), eps, silu)
+    torch.cuda.synchronize()
+    _close(out, want.reshape(-1, C), rtol=3e-3, atol=3e-3, what="groupnorm")
+
+
+def test_layernorm_variants(dev):
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(4)
+    rows, C = 37, 640
+    x, gm, bt = _rand(g, rows, C) * 2 + 0.3, _rand(g, C) + 1, _rand(g, C)
+    out = torch.empty(rows, C, dtype=torch.half, device=dev)
+    ops.layernorm(x.to(dev), out, gm.to(dev), bt.to(dev), 1e-5)
+    torch.cuda.synchronize()
+    _close(out, F.layer_norm(x.float(), (C,), gm.float(), bt.float(), 1e-5), what="ln")
+    # adaLN: 2 batches x 16 tokens, LN without affine, (1+scale), shift  (attention_processor.py:24-25)
+    x2 = _rand(g, 32, 128)
+    mod = _rand(g, 2, 256, scale=0.3)                    # [shift | scale] per batch row
+    want = F.layer_norm(x2.float(), (128,), None, None, 1e-6).reshape(2, 16, 128) * (1 + mod.float()[:, None, 128:]) \
+        + mod.float()[:, None, :128]
+    modd = mod.to(dev)
+    out2 = torch.empty(32, 128, dtype=torch.half, device=dev)
+    ops.layernorm(x2.to(dev), out2, eps=1e-6, shift=modd[:, :128], scale=modd[:, 128:], rows_per_mod=16)
+    torch.cuda.synchronize()
+    _close(out2, want.reshape(32, 128), what="adaLN")
+    outT = torch.zeros(128, 2 * 16, dtype=torch.half, device=dev)
+    ops.layernorm(x2.to(dev), outT, eps=1e-6, shift=modd[:, :128], scale=modd[:, 128:], rows_per_mod=16, transposed=True,
+                  tr_rows=16, tr_bstride=16)
+    torch.cuda.synchronize()
+    _close(outT, want.reshape(32, 128).T, what="adaLN^T")
+
+
+def test_pointwise(dev):
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(8)
+    # sinusoid: [cos | sin], module/min_sdxl.py:205-224
+    vals = torch.tensor([[958.0, 1024.0, 0.0], [1.0, 512.0, 3.0]])
+    out = torch.zeros(2, 3 * 64 + 8, dtype=torch.half, device=dev)
+    ops.sinusoid(vals.to(dev), out, 64, col_off=8)
+    k = torch.arange(32, dtype=torch.float32)
+    ang = vals.reshape(-1, 1) * torch.exp(-math.log(10000) * k / 32)[None]
+    want = torch.cat([ang.cos(), ang.sin()], -1).reshape(2, 192)
+    torch.cuda.synchronize()
+    _close(out[:, 8:], want, rtol=2e-3, atol=2e-3, what="sinusoid")
+    # silu, copy_add, transpose
+    x = _rand(g, 40, 64)
+    y = torch.empty(40, 64, dtype=torch.half, device=dev)
+    ops.silu(x.to(dev), y)
+    _close(y, F.silu(x.float()), what="silu")
+    dst = torch.zeros(40, 192, dtype=torch.half, device=dev)
+    add = _rand(g, 40, 64)
+    sc = torch.tensor([0.5, 2.0], device=dev)
+    ops.copy_add(x.to(dev), dst, dst_off=128, add=add.to(dev), add_scale=sc, rows_per_scale=20)
+    want = x.float() + add.float() * torch.tensor([0.5] * 20 + [2.0] * 20)[:, None]
+    torch.cuda.synchronize()
+    _close(dst[:, 128:], want, what="copy_add")
+    assert dst[:, :128].abs().max().item() == 0
+    t = torch.full((64, 48), 7.0, dtype=torch.half, device=dev)
+    ops.transpose(x.to(dev), t, rows_pad=48)
+    torch.cuda.synchronize()
+    assert torch.equal(t[:, :40].cpu(), x.T) and t[:, 40:].abs().max().item() == 0
