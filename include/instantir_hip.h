@@ -30,6 +30,7 @@ extern "C" {
 #define IIR_EPI_SFT 2   /* C[:, j] = res[:, j] * (acc_gamma + b + 1) + (acc_beta + b)             */
 #define IIR_ACT_NONE 0
 #define IIR_ACT_SILU 1
+#define IIR_ACT_GELU 2 /* erf form */
 
 /* Pair permutation expected by GEGLU / SFT epilogues: for an op with `n_out` outputs whose
  * "value" rows are V[0..n_out) and partner rows are G[0..n_out), the weight (and bias) handed to
@@ -68,6 +69,9 @@ typedef struct iir_conv_desc {
     float out_scale;
     int32_t tile;
     const void* zero_page;         /* >= 128 zero bytes: source of the padding pixels              */
+    int64_t x_img_stride;          /* elements between input images; 0 = H*Wd*ldx (dense)          */
+    int32_t y_img_rows;            /* rows between images in Y; 0 = Ho*Wo (dense)                  */
+    int32_t res_img_rows;          /* rows between images in res; 0 = Ho*Wo                        */
 } iir_conv_desc;
 
 /* Replaces nn.Conv2d call sites: ResnetBlock2D module/min_sdxl.py:256-259,274 (+ the temb add :267 as

@@ -36,6 +36,8 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     // conv
     int H, Wd, Cin, Ho, Wo, ks, stride, pad, ups;
     const f16* zero;
+    long x_img_stride;        // elements between input images
+    int y_img_rows, res_img_rows;   // rows between images in C / res (conv mode); 0 = dense
     int tiles_m, tiles_n;
 };
 
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
             const int hw = g.Ho * g.Wo;
             const int img = m / hw, rem = m - img * hw;
             const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-            a_img[i] = g.A + (long)img * g.H * g.Wd * g.lda + schunk * 8;
+            a_img[i] = g.A + (long)img * g.x_img_stride + schunk * 8;
             a_pix_y[i] = oy * g.stride - g.pad;
             a_pix_x[i] = ox * g.stride - g.pad;
         }
@@ -169,6 +171,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
         const int m = m0 + wm * WM + i * 16 + frow;
         if (m >= g.M) continue;
         const f16* rb = g.rowbias ? g.rowbias + (long)(m / g.rows_per_rb) * g.ldrb : nullptr;
+        long mc = m, mr = m;                       // row of this output in C and in res
+        if (CONV && (g.y_img_rows | g.res_img_rows)) {
+            const int hw = g.Ho * g.Wo, img = m / hw, rem = m - img * hw;
+            if (g.y_img_rows) mc = (long)img * g.y_img_rows + rem;
+            if (g.res_img_rows) mr = (long)img * g.res_img_rows + rem;
+        }
         if (g.epi == IIR_EPI_PLAIN) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
@@ -178,10 +186,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 if (g.bias) { f16x4 b = *(const f16x4*)(g.bias + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (rb) { f16x4 b = *(const f16x4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
-                if (g.res) { f16x4 r = *(const f16x4*)(g.res + (long)m * g.ldr + n); for (int t = 0; t < 4; ++t) v[t] += (float)r[t]; }
+                else if (g.act == IIR_ACT_GELU) for (int t = 0; t < 4; ++t) v[t] = gelu_erf_f(v[t]);
+                if (g.res) { f16x4 r = *(const f16x4*)(g.res + mr * g.ldr + n); for (int t = 0; t < 4; ++t) v[t] += (float)r[t]; }
                 f16x4 o;
                 for (int t = 0; t < 4; ++t) o[t] = (f16)(v[t] * g.out_scale);
-                *(f16x4*)(g.C + (long)m * g.ldc + n) = o;
+                *(f16x4*)(g.C + mc * g.ldc + n) = o;
             }
         } else {
             // paired columns: in every 32-column group of the (row-permuted) weight the first 16 are
@@ -201,10 +210,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 if (g.epi == IIR_EPI_GEGLU) {
                     for (int t = 0; t < 4; ++t) o[t] = (f16)(a[t] * gelu_erf_f(b[t]));
                 } else {   // IIR_EPI_SFT: h * (gamma + 1) + beta, h from `res`
-                    f16x4 h = *(const f16x4*)(g.res + (long)m * g.ldr + no);
+                    f16x4 h = *(const f16x4*)(g.res + mr * g.ldr + no);
                     for (int t = 0; t < 4; ++t) o[t] = (f16)((float)h[t] * (a[t] + 1.0f) + b[t]);
                 }
-                *(f16x4*)(g.C + (long)m * g.ldc + no) = o;
+                *(f16x4*)(g.C + mc * g.ldc + no) = o;
             }
         }
     }
@@ -285,5 +294,7 @@ extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
     g.out_scale = c->out_scale == 0.f ? 1.f : c->out_scale;
     g.H = c->H; g.Wd = c->Wd; g.Cin = c->Cin; g.ks = c->ksize; g.stride = c->stride; g.pad = pad; g.ups = c->upsample;
     g.zero = (const f16*)c->zero_page;
+    g.x_img_stride = c->x_img_stride ? c->x_img_stride : (int64_t)c->H * c->Wd * c->ldx;
+    g.y_img_rows = c->y_img_rows; g.res_img_rows = c->res_img_rows;
     return dispatch(g, true, c->tile, (hipStream_t)stream);
 }

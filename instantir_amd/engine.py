@@ -1,0 +1,620 @@
+"""MI355X executors for the two networks of the InstantIR step: SDXL UNet with TA-IP decoupled
+cross-attention (`HipUNet`) and the Aggregator (`HipAggregator`).
+
+Python here only sequences C-ABI kernel launches (instantir_amd.ops) over pre-packed fp16 weights
+and a bump-allocated activation arena; every launch goes to torch's current stream, so a whole
+denoising step can be captured into a hipGraph by the caller.  There is no torch arithmetic on
+the forward path.
+
+Reference behaviour reproduced (citations to /root/reference):
+  * UNet forward: module/unet/unet_2d_ZeroSFT.py:1226-1388 structure with stock-diffusers additive
+    ControlNet residuals; leaf math module/min_sdxl.py:242-283 (resnet),
+    :531-595 (transformer), :598-618 (down/upsample).
+  * attention processors: module/ip_adapter/attention_processor.py:337-414, :1093-1207, :6-26.
+  * Aggregator: module/aggregator.py:758-977 (+ SFT :70-90, zero 1x1 :414-417), attn2 removed
+    (pipelines/sdxl_instantir.py:165-177).
+  * Resampler: module/ip_adapter/resampler.py:34-78,127-147 via MultiIPAdapterImageProjection
+    (module/ip_adapter/ip_adapter.py:68-90).
+
+MI355X-first restructuring (observable results unchanged):
+  * NHWC activations: a feature map IS its token matrix; no permutes around Transformer2D.
+  * step-invariant work hoisted out of the step: Resampler, text K/V
+    projections, to_k_ip/to_v_ip projections, add_embedding branch.
+  * all resnet time_emb_proj linears and all adaLN linears of a network are each ONE GEMM per forward.
+  * q|k projections fused into one GEMM; V is produced transposed (V^T = Wv . X^T) for the
+    attention kernel; GEGLU, SiLU, bias, temb add and residual adds live in GEMM/conv epilogues;
+    skip concatenation is written in place by the producer and the ControlNet residual add is
+    folded into the skip copy.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .config import UNetConfig
+from .packing import conv_weight_nhwc, pair_rows
+from .weights import skip_channels
+
+F16 = torch.float16
+CPAD = 64          # latent channels are zero-padded to one K tile
+
+
+class _NullOps:
+    """Stand-in for `ops` during the arena-sizing dry run: every launch is skipped."""
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+class Arena:
+    """Bump allocator over one fp16 device buffer.  Static op order => static addresses, which is
+    what hipGraph capture needs."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+        self.off = 0
+        self.high = 0
+
+    def reserve(self, n_elems):
+        self.buf = torch.empty(n_elems, dtype=F16, device=self.device)
+
+    def alloc(self, rows, cols):
+        n = (rows * cols + 127) // 128 * 128
+        off = self.off
+        self.off += n
+        self.high = max(self.high, self.off)
+        if self.buf is None:      # dry run: hand out a meta view so shapes/strides still work
+            return torch.empty(rows, cols, dtype=F16, device="meta")
+        if self.off > self.buf.numel():
+            raise RuntimeError("activation arena overflow (forward differs from its sizing run)")
+        return self.buf[off:off + rows * cols].view(rows, cols)
+
+    def mark(self):
+        return self.off
+
+    def release(self, m):
+        self.off = m
+
+    def reset(self):
+        self.off = 0
+
+
+def _merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], scaling: float) -> Dict[str, torch.Tensor]:
+    """W' = W + s * B A (linear) / W'[o,i,:,:] = W + s * sum_r B[o,r] A[r,i,:,:] (conv): the enabled-adapter
+    forward of peft folded into a second weight copy, merged in fp32."""
+    out = dict(sd)
+    for k in lora:
+        if not k.endswith(".lora_A.weight"):
+            continue
+        path = k[: -len(".lora_A.weight")]
+        a, b = lora[k].float(), lora[path + ".lora_B.weight"].float()
+        w = sd[path + ".weight"].float()
+        if w.dim() == 2:
+            w = w + scaling * (b @ a)
+        else:
+            w = w + scaling * torch.einsum("or,rikl->oikl", b[:, :, 0, 0], a)
+        out[path + ".weight"] = w.to(sd[path + ".weight"].dtype)
+    return out
+
+
+class _Net:
+    """Shared machinery: packed weights, arena, resnet / transformer executors."""
+
+    def __init__(self, cfg: UNetConfig, sd: Dict[str, torch.Tensor], cross: bool, device):
+        self.cfg = cfg
+        self.cross = cross
+        self.device = device
+        self.arena = Arena(device)
+        self.o = ops
+        self.w: Dict[str, torch.Tensor] = {}
+        self._temb_slices: Dict[str, slice] = {}
+        self._ada_slices: Dict[str, slice] = {}
+        self._pack_encoder(sd)
+
+    # ---- weight packing ---------------------------------------------------------------------
+    def _t(self, sd, name):
+        return sd[name].to(device=self.device, dtype=F16)
+
+    def _pack_linear(self, sd, path, dst=None):
+        dst = dst or path
+        self.w[dst + ".w"] = self._t(sd, path + ".weight").contiguous()
+        if (path + ".bias") in sd:
+            self.w[dst + ".b"] = self._t(sd, path + ".bias").contiguous()
+
+    def _pack_conv3(self, sd, path, cin_pad=None):
+        self.w[path + ".w"] = conv_weight_nhwc(self._t(sd, path + ".weight"), cin_pad)
+        self.w[path + ".b"] = self._t(sd, path + ".bias").contiguous()
+
+    def _pack_norm(self, sd, path):
+        self.w[path + ".g"] = self._t(sd, path + ".weight").contiguous()
+        self.w[path + ".b"] = self._t(sd, path + ".bias").contiguous()
+
+    def _pack_resnet(self, sd, path, temb_list):
+        self._pack_norm(sd, path + ".norm1")
+        self._pack_conv3(sd, path + ".conv1")
+        self._pack_norm(sd, path + ".norm2")
+        self._pack_conv3(sd, path + ".conv2")
+        temb_list.append((path, self._t(sd, path + ".time_emb_proj.weight"), self._t(sd, path + ".time_emb_proj.bias")))
+        if (path + ".conv_shortcut.weight") in sd:
+            w = self._t(sd, path + ".conv_shortcut.weight")
+            self.w[path + ".conv_shortcut.w"] = w.reshape(w.shape[0], w.shape[1]).contiguous()
+            self.w[path + ".conv_shortcut.b"] = self._t(sd, path + ".conv_shortcut.bias").contiguous()
+
+    def _pack_transformer(self, sd, path, depth, ada_list):
+        self._pack_norm(sd, path + ".norm")
+        self._pack_linear(sd, path + ".proj_in")
+        self._pack_linear(sd, path + ".proj_out")
+        for k in range(depth):
+            p = f"{path}.transformer_blocks.{k}"
+            self._pack_norm(sd, p + ".norm1")
+            self.w[p + ".attn1.qk.w"] = torch.cat([self._t(sd, p + ".attn1.to_q.weight"), self._t(sd, p + ".attn1.to_k.weight")], 0).contiguous()
+            self.w[p + ".attn1.v.w"] = self._t(sd, p + ".attn1.to_v.weight").contiguous()
+            self._pack_linear(sd, p + ".attn1.to_out.0")
+            if self.cross:
+                self._pack_norm(sd, p + ".norm2")
+                self._pack_linear(sd, p + ".attn2.to_q")
+                self._pack_linear(sd, p + ".attn2.to_k")
+                self._pack_linear(sd, p + ".attn2.to_v")
+                self._pack_linear(sd, p + ".attn2.to_out.0")
+                pp = p + ".attn2.processor"
+                self._pack_linear(sd, pp + ".to_k_ip")
+                self._pack_linear(sd, pp + ".to_v_ip")
+                for kv in ("k", "v"):
+                    ada_list.append((f"{p}.{kv}", self._t(sd, f"{pp}.ln_{kv}_ip.linear.weight"), self._t(sd, f"{pp}.ln_{kv}_ip.linear.bias")))
+            self._pack_norm(sd, p + ".norm3")
+            w1, b1 = self._t(sd, p + ".ff.net.0.proj.weight"), self._t(sd, p + ".ff.net.0.proj.bias")
+            n = w1.shape[0] // 2
+            self.w[p + ".ff1.w"] = pair_rows(w1[:n], w1[n:])          # GEGLU: value rows | gate rows
+            self.w[p + ".ff1.b"] = pair_rows(b1[:n], b1[n:])
+            self._pack_linear(sd, p + ".ff.net.2", p + ".ff2")
+
+    def _pack_encoder(self, sd):
+        cfg = self.cfg
+        self._temb, self._ada = [], []
+        self._pack_conv3(sd, "conv_in", CPAD)
+        for n in ("time_embedding.linear_1", "time_embedding.linear_2", "add_embedding.linear_1", "add_embedding.linear_2"):
+            self._pack_linear(sd, n)
+        nb = len(cfg.block_out_channels)
+        for i in range(nb):
+            for j in range(cfg.layers_per_block):
+                self._pack_resnet(sd, f"down_blocks.{i}.resnets.{j}", self._temb)
+                if cfg.transformer_depth[i] > 0:
+                    self._pack_transformer(sd, f"down_blocks.{i}.attentions.{j}", cfg.transformer_depth[i], self._ada)
+            if i < nb - 1:
+                self._pack_conv3(sd, f"down_blocks.{i}.downsamplers.0.conv")
+        self._pack_resnet(sd, "mid_block.resnets.0", self._temb)
+        self._pack_transformer(sd, "mid_block.attentions.0", cfg.mid_depth, self._ada)
+        self._pack_resnet(sd, "mid_block.resnets.1", self._temb)
+
+    def _finish_pack(self):
+        """Concatenate every time_emb_proj (and every adaLN linear) into one weight: one GEMM per forward."""
+        off, ws, bs = 0, [], []
+        for path, w, b in self._temb:
+            self._temb_slices[path] = slice(off, off + w.shape[0])
+            off += w.shape[0]
+            ws.append(w); bs.append(b)
+        self.w["temb_all.w"] = torch.cat(ws, 0).contiguous()
+        self.w["temb_all.b"] = torch.cat(bs, 0).contiguous()
+        if self._ada:
+            off, ws, bs = 0, [], []
+            for key, w, b in self._ada:
+                self._ada_slices[key] = slice(off, off + w.shape[0])
+                off += w.shape[0]
+                ws.append(w); bs.append(b)
+            self.w["ada_all.w"] = torch.cat(ws, 0).contiguous()
+            self.w["ada_all.b"] = torch.cat(bs, 0).contiguous()
+        del self._temb, self._ada
+
+    # ---- arena sizing -----------------------------------------------------------------------
+    def _size_arena(self, fn):
+        """Dry-run `fn` (launches skipped) to find the arena high-water mark, then allocate it."""
+        self.arena.buf, self.arena.off, self.arena.high = None, 0, 0
+        self.o = _NullOps()
+        try:
+            fn()
+        finally:
+            self.o = ops
+        self.arena.reserve(self.arena.high + 1024)
+        self.arena.reset()
+
+    # ---- blocks -----------------------------------------------------------------------------
+    def _resnet(self, path, x, R, H, W, temb_all, out=None, eps=1e-5):
+        """x (R*H*W, Cin) view -> (R*H*W, Cout).  module/min_sdxl.py:261-283."""
+        o, w, A = self.o, self.w, self.arena
+        HW = H * W
+        cin = x.shape[1]
+        cout = w[path + ".conv1.w"].shape[0]
+        if out is None:
+            out = A.alloc(R * HW, cout)
+        m = A.mark()
+        h = A.alloc(R * HW, cin)
+        o.groupnorm(x, h, R, HW, w[path + ".norm1.g"], w[path + ".norm1.b"], eps, True, self.cfg.norm_groups)
+        h2 = A.alloc(R * HW, cout)
+        o.conv2d(h.view(R, H, W, cin), w[path + ".conv1.w"], h2, bias=w[path + ".conv1.b"],
+                 rowbias=temb_all[:, self._temb_slices[path]], rows_per_rb=HW)
+        h3 = A.alloc(R * HW, cout)
+        o.groupnorm(h2, h3, R, HW, w[path + ".norm2.g"], w[path + ".norm2.b"], eps, True, self.cfg.norm_groups)
+        if (path + ".conv_shortcut.w") in w:
+            sc = A.alloc(R * HW, cout)
+            o.gemm(x, w[path + ".conv_shortcut.w"], sc, bias=w[path + ".conv_shortcut.b"])
+        else:
+            sc = x
+        o.conv2d(h3.view(R, H, W, cout), w[path + ".conv2.w"], out, bias=w[path + ".conv2.b"], res=sc)
+        A.release(m)
+        return out
+
+    def _tblock(self, p, h, R, T, heads, st, ada):
+        """One BasicTransformerBlock in place on h (R*T, C).  module/min_sdxl.py:541-562."""
+        o, w, A = self.o, self.w, self.arena
+        C = h.shape[1]
+        M = R * T
+        m = A.mark()
+        n = A.alloc(M, C)
+        # -- self-attention (AttnProcessor2_0, attention_processor.py:370-402)
+        o.layernorm(h, n, w[p + ".norm1.g"], w[p + ".norm1.b"], 1e-5)
+        qk = A.alloc(M, 2 * C)
+        o.gemm(n, w[p + ".attn1.qk.w"], qk)
+        vt = A.alloc(C, M)
+        o.gemm(w[p + ".attn1.v.w"], n, vt)                       # V^T = Wv . X^T
+        a = A.alloc(M, C)
+        o.attention(qk[:, :C], a, [(qk[:, C:], T, vt, T, T)], R, heads, T)
+        o.gemm(a, w[p + ".attn1.to_out.0.w"], h, bias=w[p + ".attn1.to_out.0.b"], res=h)
+        # -- decoupled cross-attention (TA_IPAttnProcessor2_0, attention_processor.py:1140-1195)
+        if self.cross:
+            o.layernorm(h, n, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
+            q = qk[:, :C]
+            o.gemm(n, w[p + ".attn2.to_q.w"], q)
+            cfg = self.cfg
+            nip, ipad = cfg.num_ip_tokens, (cfg.num_ip_tokens + 7) // 8 * 8
+            kv = st["kv"][p]
+            ipk = A.alloc(R * nip, C)
+            ipvt = A.alloc(C, R * ipad)
+            sk, sv = self._ada_slices[p + ".k"], self._ada_slices[p + ".v"]
+            # adaLN: shift first, then scale (attention_processor.py:24)
+            o.layernorm(kv["ipk_raw"], ipk, eps=1e-6, shift=ada[:, sk.start:sk.start + C], scale=ada[:, sk.start + C:sk.stop],
+                        rows_per_mod=nip)
+            o.layernorm(kv["ipv_raw"], ipvt, eps=1e-6, shift=ada[:, sv.start:sv.start + C], scale=ada[:, sv.start + C:sv.stop],
+                        rows_per_mod=nip, transposed=True, tr_rows=nip, tr_bstride=ipad)
+            o.attention(q, a, [(kv["tk"], cfg.text_len, kv["tvt"], kv["tpad"], cfg.text_len), (ipk, nip, ipvt, ipad, nip)],
+                        R, heads, T)
+            o.gemm(a, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h)
+        # -- GEGLU feed-forward (module/min_sdxl.py:502-528)
+        o.layernorm(h, n, w[p + ".norm3.g"], w[p + ".norm3.b"], 1e-5)
+        f = A.alloc(M, 4 * C)
+        o.gemm(n, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU)
+        o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h)
+        A.release(m)
+
+    def _transformer(self, path, x, depth, R, H, W, st, ada, out=None):
+        """Transformer2DModel on the NHWC map x (R*H*W, C).  module/min_sdxl.py:578-595."""
+        o, w, A = self.o, self.w, self.arena
+        C = x.shape[1]
+        T = H * W
+        if out is None:
+            out = A.alloc(R * T, C)
+        m = A.mark()
+        g = A.alloc(R * T, C)
+        o.groupnorm(x, g, R, T, w[path + ".norm.g"], w[path + ".norm.b"], 1e-6, False, self.cfg.norm_groups)
+        h = A.alloc(R * T, C)
+        o.gemm(g, w[path + ".proj_in.w"], h, bias=w[path + ".proj_in.b"])
+        for k in range(depth):
+            self._tblock(f"{path}.transformer_blocks.{k}", h, R, T, C // self.cfg.head_dim, st, ada)
+        o.gemm(h, w[path + ".proj_out.w"], out, bias=w[path + ".proj_out.b"], res=x)
+        A.release(m)
+        return out
+
+    def _embeddings(self, t_dev, st):
+        """silu(emb) shared by every consumer, the batched time_emb_proj and adaLN GEMMs.
+        emb = time_embedding(sincos(t)) + aug_emb (module/unet/unet_2d_ZeroSFT.py:1226-1243)."""
+        o, w, A, cfg = self.o, self.w, self.arena, self.cfg
+        R = st["R"]
+        c0, td = cfg.block_out_channels[0], cfg.time_embed_dim
+        sin = A.alloc(R, c0)
+        o.sinusoid(t_dev, sin, c0)
+        e1 = A.alloc(R, td)
+        o.gemm(sin, w["time_embedding.linear_1.w"], e1, bias=w["time_embedding.linear_1.b"], act=ops.ACT_SILU)
+        emb = A.alloc(R, td)
+        o.gemm(e1, w["time_embedding.linear_2.w"], emb, bias=w["time_embedding.linear_2.b"], res=st["aug_emb"])
+        act = A.alloc(R, td)
+        o.silu(emb, act)
+        temb_all = A.alloc(R, w["temb_all.w"].shape[0])
+        o.gemm(act, w["temb_all.w"], temb_all, bias=w["temb_all.b"])
+        ada = None
+        if "ada_all.w" in w:
+            ada = A.alloc(R, w["ada_all.w"].shape[0])
+            o.gemm(act, w["ada_all.w"], ada, bias=w["ada_all.b"])
+        return temb_all, ada
+
+    def _aug_emb(self, text_embeds, time_ids):
+        """add_embedding(cat(pooled, sincos(time_ids))) -- step invariant."""
+        cfg, w = self.cfg, self.w
+        R = text_embeds.shape[0]
+        a = torch.zeros(R, cfg.add_embed_in, dtype=F16, device=self.device)
+        a[:, :cfg.pooled_dim] = text_embeds.to(self.device, F16)
+        ops.sinusoid(time_ids.to(self.device, torch.float32).contiguous(), a, cfg.addition_time_embed_dim, col_off=cfg.pooled_dim)
+        h = torch.empty(R, cfg.time_embed_dim, dtype=F16, device=self.device)
+        ops.gemm(a, w["add_embedding.linear_1.w"], h, bias=w["add_embedding.linear_1.b"], act=ops.ACT_SILU)
+        out = torch.empty(R, cfg.time_embed_dim, dtype=F16, device=self.device)
+        ops.gemm(h, w["add_embedding.linear_2.w"], out, bias=w["add_embedding.linear_2.b"])
+        return out
+
+    def _down_and_mid(self, x, R, H, W, temb_all, ada, st):
+        """conv_in output -> (mid output, skips with their (H, W)).  module/min_sdxl.py:620-677,757-779."""
+        cfg, o, w, A = self.cfg, self.o, self.w, self.arena
+        skips = [(x, H, W)]
+        nb = len(cfg.block_out_channels)
+        for i, c in enumerate(cfg.block_out_channels):
+            for j in range(cfg.layers_per_block):
+                x = self._resnet(f"down_blocks.{i}.resnets.{j}", x, R, H, W, temb_all)
+                if cfg.transformer_depth[i] > 0:
+                    x = self._transformer(f"down_blocks.{i}.attentions.{j}", x, cfg.transformer_depth[i], R, H, W, st, ada)
+                skips.append((x, H, W))
+            if i < nb - 1:
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                H2, W2 = (H + 1) // 2, (W + 1) // 2
+                y = A.alloc(R * H2 * W2, c)
+                o.conv2d(x.view(R, H, W, c), w[p + ".w"], y, stride=2, bias=w[p + ".b"])
+                x, H, W = y, H2, W2
+                skips.append((x, H, W))
+        x = self._resnet("mid_block.resnets.0", x, R, H, W, temb_all)
+        x = self._transformer("mid_block.attentions.0", x, cfg.mid_depth, R, H, W, st, ada)
+        x = self._resnet("mid_block.resnets.1", x, R, H, W, temb_all)
+        return x, H, W, skips
+
+
+class HipUNet(_Net):
+    """SDXL UNet with TA-IP cross-attention.  `lora`/`lora_scaling` build the previewer weight set."""
+
+    def __init__(self, cfg: UNetConfig, sd: Dict[str, torch.Tensor], device, lora=None, lora_scaling=1.0):
+        if lora is not None:
+            sd = _merge_lora({k: v.to(device) for k, v in sd.items()}, {k: v.to(device) for k, v in lora.items()}, lora_scaling)
+        super().__init__(cfg, sd, True, device)
+        skips = skip_channels(cfg)
+        rev = list(reversed(cfg.block_out_channels))
+        depth = list(reversed(cfg.transformer_depth))
+        for i, c in enumerate(rev):
+            for j in range(cfg.layers_per_block + 1):
+                self._pack_resnet(sd, f"up_blocks.{i}.resnets.{j}", self._temb)
+                if depth[i] > 0:
+                    self._pack_transformer(sd, f"up_blocks.{i}.attentions.{j}", depth[i], self._ada)
+            if i < len(rev) - 1:
+                self._pack_conv3(sd, f"up_blocks.{i}.upsamplers.0.conv")
+        self._pack_norm(sd, "conv_norm_out")
+        self._pack_conv3(sd, "conv_out")
+        self._finish_pack()
+        self._pack_resampler(sd)
+        self._sized = None
+
+    # ---- Resampler (runs once per image batch) ------------------------------------------------
+    def _pack_resampler(self, sd):
+        rc = self.cfg.resampler
+        p = "encoder_hid_proj.image_projection_layers.0"
+        self.w["rs.latents"] = self._t(sd, p + ".latents").reshape(rc.num_queries, rc.dim).contiguous()
+        self._pack_linear(sd, p + ".proj_in", "rs.proj_in")
+        self._pack_linear(sd, p + ".proj_out", "rs.proj_out")
+        self._pack_norm(sd, p + ".norm_out")
+        self.w["rs.norm_out.g"], self.w["rs.norm_out.b"] = self.w.pop(p + ".norm_out.g"), self.w.pop(p + ".norm_out.b")
+        for i in range(rc.depth):
+            a, f = f"{p}.layers.{i}.0", f"{p}.layers.{i}.1"
+            for nn_ in ("norm1", "norm2"):
+                self.w[f"rs.{i}.{nn_}.g"] = self._t(sd, f"{a}.{nn_}.weight").contiguous()
+                self.w[f"rs.{i}.{nn_}.b"] = self._t(sd, f"{a}.{nn_}.bias").contiguous()
+            self.w[f"rs.{i}.to_q.w"] = self._t(sd, a + ".to_q.weight").contiguous()
+            self.w[f"rs.{i}.to_kv.w"] = self._t(sd, a + ".to_kv.weight").contiguous()
+            self.w[f"rs.{i}.to_out.w"] = self._t(sd, a + ".to_out.weight").contiguous()
+            self.w[f"rs.{i}.ffn.g"] = self._t(sd, f + ".0.weight").contiguous()
+            self.w[f"rs.{i}.ffn.b"] = self._t(sd, f + ".0.bias").contiguous()
+            self.w[f"rs.{i}.ff1.w"] = self._t(sd, f + ".1.weight").contiguous()
+            self.w[f"rs.{i}.ff2.w"] = self._t(sd, f + ".3.weight").contiguous()
+
+    def resampler(self, image_embeds: torch.Tensor) -> torch.Tensor:
+        """(n, B, S, E) DINOv2 features -> (n*B, Q, D) IP tokens.  resampler.py:127-147, ip_adapter.py:81-86."""
+        rc, w, dev = self.cfg.resampler, self.w, self.device
+        x = image_embeds.to(dev, F16)
+        Rr = x.shape[0] * x.shape[1]
+        S = x.shape[2]
+        x = x.reshape(Rr * S, x.shape[3]).contiguous()
+        Q, D, inner, heads = rc.num_queries, rc.dim, rc.dim_head * rc.heads, rc.heads
+        new = lambda r, c: torch.empty(r, c, dtype=F16, device=dev)
+        xp = new(Rr * S, D)
+        ops.gemm(x, w["rs.proj_in.w"], xp, bias=w["rs.proj_in.b"])
+        lat = w["rs.latents"].repeat(Rr, 1).contiguous()                       # (Rr*Q, D)
+        Tkv = S + Q
+        tpad = (Tkv + 7) // 8 * 8
+        cat = new(Rr * Tkv, D)
+        cat3 = cat.view(Rr, Tkv, D)
+        for i in range(rc.depth):
+            # PerceiverAttention (resampler.py:50-78): kv input = cat(norm1(x), norm2(latents))
+            for r in range(Rr):
+                ops.layernorm(xp[r * S:(r + 1) * S], cat3[r, :S], w[f"rs.{i}.norm1.g"], w[f"rs.{i}.norm1.b"], 1e-5)
+                ops.layernorm(lat[r * Q:(r + 1) * Q], cat3[r, S:], w[f"rs.{i}.norm2.g"], w[f"rs.{i}.norm2.b"], 1e-5)
+            ln_lat = new(Rr * Q, D)
+            ops.layernorm(lat, ln_lat, w[f"rs.{i}.norm2.g"], w[f"rs.{i}.norm2.b"], 1e-5)
+            q = new(Rr * Q, inner)
+            ops.gemm(ln_lat, w[f"rs.{i}.to_q.w"], q)
+            kvb = new(Rr * Tkv, 2 * inner)
+            ops.gemm(cat, w[f"rs.{i}.to_kv.w"], kvb)
+            vt = torch.zeros(inner, Rr * tpad, dtype=F16, device=dev)
+            for r in range(Rr):
+                ops.transpose(kvb[r * Tkv:(r + 1) * Tkv, inner:], vt[:, r * tpad:(r + 1) * tpad], tpad)
+            a = new(Rr * Q, inner)
+            # (q d^-1/4)(k d^-1/4)^T = q k^T / sqrt(d); softmax in fp32 (resampler.py:72-74)
+            ops.attention(q, a, [(kvb[:, :inner], Tkv, vt, tpad, Tkv)], Rr, heads, Q, scale=rc.dim_head ** -0.5)
+            lat2 = new(Rr * Q, D)
+            ops.gemm(a, w[f"rs.{i}.to_out.w"], lat2, res=lat)
+            # FeedForward (resampler.py:13-20): LN, Linear, GELU, Linear, no biases
+            h = new(Rr * Q, D)
+            ops.layernorm(lat2, h, w[f"rs.{i}.ffn.g"], w[f"rs.{i}.ffn.b"], 1e-5)
+            f = new(Rr * Q, D * rc.ff_mult)
+            ops.gemm(h, w[f"rs.{i}.ff1.w"], f, act=ops.ACT_GELU)
+            lat = new(Rr * Q, D)
+            ops.gemm(f, w[f"rs.{i}.ff2.w"], lat, res=lat2)
+        po = new(Rr * Q, rc.output_dim)
+        ops.gemm(lat, w["rs.proj_out.w"], po, bias=w["rs.proj_out.b"])
+        out = new(Rr * Q, rc.output_dim)
+        ops.layernorm(po, out, w["rs.norm_out.g"], w["rs.norm_out.b"], 1e-5)
+        return out.view(Rr, Q, rc.output_dim)
+
+    # ---- per-batch preparation ----------------------------------------------------------------
+    def prepare(self, ctx, text_embeds, time_ids, ip_tokens, H, W):
+        """Hoist everything that does not depend on the step: aug_emb, text K / V^T and raw IP K / V
+        projections of every cross-attention block.  ctx (R, L, Dc); ip_tokens (R, Q, Dc)."""
+        cfg, w, dev = self.cfg, self.w, self.device
+        R, L = ctx.shape[0], ctx.shape[1]
+        assert L == cfg.text_len and ip_tokens.shape[1] == cfg.num_ip_tokens
+        ctx2 = ctx.to(dev, F16).reshape(R * L, -1).contiguous()
+        ip2 = ip_tokens.to(dev, F16).reshape(R * cfg.num_ip_tokens, -1).contiguous()
+        tpad = (L + 7) // 8 * 8
+        st = {"R": R, "H": H, "W": W, "aug_emb": self._aug_emb(text_embeds, time_ids), "kv": {}}
+        blocks = sorted({k[: -len(".attn2.to_k.w")] for k in w if k.endswith(".attn2.to_k.w")})
+        for p in blocks:
+            C = w[p + ".attn2.to_k.w"].shape[0]
+            tk = torch.empty(R * L, C, dtype=F16, device=dev)
+            ops.gemm(ctx2, w[p + ".attn2.to_k.w"], tk)
+            tv = torch.empty(R * L, C, dtype=F16, device=dev)
+            ops.gemm(ctx2, w[p + ".attn2.to_v.w"], tv)
+            tvt = torch.zeros(C, R * tpad, dtype=F16, device=dev)
+            for r in range(R):
+                ops.transpose(tv[r * L:(r + 1) * L], tvt[:, r * tpad:(r + 1) * tpad], tpad)
+            ipk = torch.empty(R * cfg.num_ip_tokens, C, dtype=F16, device=dev)
+            ops.gemm(ip2, w[p + ".attn2.processor.to_k_ip.w"], ipk)
+            ipv = torch.empty(R * cfg.num_ip_tokens, C, dtype=F16, device=dev)
+            ops.gemm(ip2, w[p + ".attn2.processor.to_v_ip.w"], ipv)
+            st["kv"][p] = {"tk": tk, "tvt": tvt, "tpad": tpad, "ipk_raw": ipk, "ipv_raw": ipv}
+        key = (R, H, W)
+        if self._sized != key:
+            dummy = torch.empty(R * H * W, CPAD, dtype=F16, device="meta")
+            self._size_arena(lambda: self._forward(dummy, None, st, None, None, None))
+            self._sized = key
+        return st
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, sample, t_dev, st, down_res=None, mid_res=None, res_scale=None):
+        """sample: (R*H*W, 64) fp16 NHWC latent (channels >= 4 zero).  t_dev: fp32 device tensor (R, 1).
+        down_res: list of (R*h*w, C) tensors added to the skips; mid_res likewise; res_scale: fp32 device (R,)
+        per-row scale of the residuals (cond_scale, pipelines/sdxl_instantir.py:1602-1603).
+        Returns eps as an (R*H*W, 4) fp16 NHWC view into the arena (valid until the next forward)."""
+        self.arena.reset()
+        return self._forward(sample, t_dev, st, down_res, mid_res, res_scale)
+
+    def _forward(self, sample, t_dev, st, down_res, mid_res, res_scale):
+        cfg, o, w, A = self.cfg, self.o, self.w, self.arena
+        R, H, W = st["R"], st["H"], st["W"]
+        temb_all, ada = self._embeddings(t_dev, st)
+        x = A.alloc(R * H * W, cfg.block_out_channels[0])
+        o.conv2d(sample.view(R, H, W, CPAD), w["conv_in.w"], x, bias=w["conv_in.b"])
+        x, h, wd, skips = self._down_and_mid(x, R, H, W, temb_all, ada, st)
+        rev = list(reversed(cfg.block_out_channels))
+        depth = list(reversed(cfg.transformer_depth))
+        nb = len(rev)
+        pending_mid = mid_res            # added to the mid output when it is copied into the first concat
+        for i, c in enumerate(rev):
+            for j in range(cfg.layers_per_block + 1):
+                sk, sh, sw = skips.pop()
+                k = len(skips)           # index of this skip in push order
+                cx, cs = x.shape[1], sk.shape[1]
+                cat = A.alloc(R * h * wd, cx + cs)
+                # torch.cat([hidden, skip], dim=1) (module/min_sdxl.py:712) written in place; ControlNet
+                # residuals (stock diffusers: skip + residual) folded into the copies.
+                o.copy_add(x, cat, 0, add=pending_mid, add_scale=res_scale if pending_mid is not None else None,
+                           rows_per_scale=h * wd)
+                pending_mid = None
+                o.copy_add(sk, cat, cx, add=down_res[k] if down_res is not None else None,
+                           add_scale=res_scale if down_res is not None else None, rows_per_scale=h * wd)
+                x = self._resnet(f"up_blocks.{i}.resnets.{j}", cat, R, h, wd, temb_all)
+                if depth[i] > 0:
+                    x = self._transformer(f"up_blocks.{i}.attentions.{j}", x, depth[i], R, h, wd, st, ada)
+            if i < nb - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                y = A.alloc(R * 4 * h * wd, c)
+                o.conv2d(x.view(R, h, wd, c), w[p + ".w"], y, upsample=True, bias=w[p + ".b"])
+                x, h, wd = y, 2 * h, 2 * wd
+        c0 = cfg.block_out_channels[0]
+        g = A.alloc(R * h * wd, c0)
+        o.groupnorm(x, g, R, h * wd, w["conv_norm_out.g"], w["conv_norm_out.b"], 1e-5, True, cfg.norm_groups)
+        eps = A.alloc(R * h * wd, cfg.out_channels)
+        o.conv2d(g.view(R, h, wd, c0), w["conv_out.w"], eps, bias=w["conv_out.b"])
+        return eps
+
+
+class HipAggregator(_Net):
+    """Aggregator: SDXL encoder half on the (2H x W) concat of LQ latent and preview, SFT heads."""
+
+    def __init__(self, cfg: UNetConfig, sd: Dict[str, torch.Tensor], device):
+        super().__init__(cfg, sd, False, device)
+        self._pack_conv3(sd, "ref_conv_in", CPAD)
+        names = [f"controlnet_down_blocks.{k}" for k in range(len(skip_channels(cfg)))] + ["controlnet_mid_block"]
+        for p in names:
+            w0 = conv_weight_nhwc(self._t(sd, p + ".0.mlp_shared.0.weight"))
+            self.w[p + ".shared.w"], self.w[p + ".shared.b"] = w0, self._t(sd, p + ".0.mlp_shared.0.bias").contiguous()
+            wm, wa = conv_weight_nhwc(self._t(sd, p + ".0.mul.weight")), conv_weight_nhwc(self._t(sd, p + ".0.add.weight"))
+            self.w[p + ".ga.w"] = pair_rows(wm, wa)                       # gamma rows | beta rows
+            self.w[p + ".ga.b"] = pair_rows(self._t(sd, p + ".0.mul.bias"), self._t(sd, p + ".0.add.bias"))
+            w1 = self._t(sd, p + ".1.weight")
+            self.w[p + ".zero.w"] = w1.reshape(w1.shape[0], w1.shape[1]).contiguous()
+            self.w[p + ".zero.b"] = self._t(sd, p + ".1.bias").contiguous()
+        self._finish_pack()
+        self._sized = None
+        self._out: Optional[List[torch.Tensor]] = None
+
+    def prepare(self, text_embeds, time_ids, H, W):
+        R = text_embeds.shape[0]
+        st = {"R": R, "H": H, "W": W, "aug_emb": self._aug_emb(text_embeds, time_ids), "kv": {}}
+        key = (R, H, W)
+        if self._sized != key:
+            # residual outputs live outside the arena: they are consumed by the following UNet forward
+            cfgc = skip_channels(self.cfg)
+            hs, h, wd = [], H, W
+            hs.append((h, wd))
+            for i in range(len(self.cfg.block_out_channels)):
+                hs += [(h, wd)] * self.cfg.layers_per_block
+                if i < len(self.cfg.block_out_channels) - 1:
+                    h, wd = (h + 1) // 2, (wd + 1) // 2
+                    hs.append((h, wd))
+            self._out = [torch.empty(R * a * b, c, dtype=F16, device=self.device) for (a, b), c in zip(hs, cfgc)]
+            self._out_mid = torch.empty(R * h * wd, self.cfg.block_out_channels[-1], dtype=F16, device=self.device)
+            dummy = torch.empty(R * H * W, CPAD, dtype=F16, device="meta")
+            self._size_arena(lambda: self._forward(dummy, dummy, None, st))
+            self._sized = key
+        return st
+
+    def forward(self, lq, preview, t_dev, st):
+        """lq, preview: (R*H*W, 64) fp16 NHWC latents.  Returns (list of 9 residuals, mid residual),
+        each (R*h*w, C) fp16 NHWC, un-scaled (conditioning_scale = 1, module/aggregator.py:963-964)."""
+        self.arena.reset()
+        return self._forward(lq, preview, t_dev, st)
+
+    def _sft(self, p, s, R, h2, wd, out):
+        """SFT + zero 1x1 on a (R, 2h, w, C) map: cond = top half, h = bottom half.
+        module/aggregator.py:940-948, :76-86."""
+        o, w, A, cfg = self.o, self.w, self.arena, self.cfg
+        C = s.shape[1]
+        h = h2 // 2
+        m = A.mark()
+        s4 = s.view(R, h2, wd, C)
+        actv = A.alloc(R * h * wd, cfg.sft_hidden)
+        o.conv2d(s4[:, :h], w[p + ".shared.w"], actv, bias=w[p + ".shared.b"], act=ops.ACT_SILU)
+        mod = A.alloc(R * h * wd, C)
+        ref = s[h * wd:]                                   # row 0 of image 0's bottom half; image stride 2*h*w rows
+        o.conv2d(actv.view(R, h, wd, cfg.sft_hidden), w[p + ".ga.w"], mod, bias=w[p + ".ga.b"], res=ref, epi=ops.EPI_SFT,
+                 res_img_rows=h2 * wd)
+        o.gemm(mod, w[p + ".zero.w"], out, bias=w[p + ".zero.b"])
+        A.release(m)
+
+    def _forward(self, lq, preview, t_dev, st):
+        cfg, o, w, A = self.cfg, self.o, self.w, self.arena
+        R, H, W = st["R"], st["H"], st["W"]
+        temb_all, ada = self._embeddings(t_dev, st)
+        c0 = cfg.block_out_channels[0]
+        x = A.alloc(R * 2 * H * W, c0)
+        # torch.cat([conv_in(lq), ref_conv_in(preview)], dim=-2)  (module/aggregator.py:889-902)
+        o.conv2d(lq.view(R, H, W, CPAD), w["conv_in.w"], x, bias=w["conv_in.b"], y_img_rows=2 * H * W)
+        o.conv2d(preview.view(R, H, W, CPAD), w["ref_conv_in.w"], x[H * W:], bias=w["ref_conv_in.b"], y_img_rows=2 * H * W)
+        xm, h2, wd, skips = self._down_and_mid(x, R, 2 * H, W, temb_all, ada, st)
+        for k, (s, sh, sw) in enumerate(skips):
+            self._sft(f"controlnet_down_blocks.{k}", s, R, sh, sw, self._out[k])
+        self._sft("controlnet_mid_block", xm, R, h2, wd, self._out_mid)
+        return self._out, self._out_mid

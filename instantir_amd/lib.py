@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libinstantir_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "instantir_hip.h")
 
 EPI_PLAIN, EPI_GEGLU, EPI_SFT = 0, 1, 2
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 
 class GemmDesc(C.Structure):
@@ -47,6 +47,7 @@ class ConvDesc(C.Structure):
         ("out_scale", C.c_float),
         ("tile", C.c_int32),
         ("zero_page", C.c_void_p),
+        ("x_img_stride", C.c_int64), ("y_img_rows", C.c_int32), ("res_img_rows", C.c_int32),
     ]
 
 

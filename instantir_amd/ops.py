@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_SFT  # noqa: F401
+from .lib import ACT_GELU, ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_SFT  # noqa: F401
 
 
 def _stream():
@@ -67,11 +67,12 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
 
 
 def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None, rows_per_rb=1, res=None,
-           epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0, tile=0):
-    """x (R,H,W,Cin) NHWC view (pixel stride x.stride(2)), w (Cout,k,k,Cin) contiguous, out (R*Ho*Wo, Cout[/2]) 2-D view."""
+           epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0, tile=0, y_img_rows=0, res_img_rows=0):
+    """x (R,H,W,Cin) NHWC view (pixel stride x.stride(2), image stride x.stride(0) free), w (Cout,k,k,Cin) contiguous,
+    out (rows, Cout[/2]) 2-D view; image i's pixels start at row i*y_img_rows (0 = dense)."""
     R, H, Wd, Cin = x.shape
-    if x.dtype != torch.float16 or x.stride(3) != 1 or x.stride(1) != Wd * x.stride(2) or x.stride(0) != H * Wd * x.stride(2):
-        raise ValueError("x must be a dense NHWC fp16 view (only the pixel stride may exceed Cin)")
+    if x.dtype != torch.float16 or x.stride(3) != 1 or x.stride(1) != Wd * x.stride(2):
+        raise ValueError("x must be an NHWC fp16 view with dense rows (pixel and image strides are free)")
     _chk2d(out, "out")
     Cout = w.shape[0]
     if tuple(w.shape[1:]) != (ksize, ksize, Cin) or not w.is_contiguous():
@@ -91,6 +92,7 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
         d.res, d.ldr = res.data_ptr(), res.stride(0)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     d.zero_page = zero_page(x.device).data_ptr()
+    d.x_img_stride, d.y_img_rows, d.res_img_rows = x.stride(0), y_img_rows, res_img_rows
     L.check(L.load().iir_conv2d_nhwc_f16(C.byref(d), _stream()), "iir_conv2d_nhwc_f16")
     return out
 
