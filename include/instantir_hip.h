@@ -139,6 +139,12 @@ int iir_sched_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int3
 int iir_lcm_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t rep, int32_t C, int32_t HW, const float* coef,
                  const float* x, void* out_nhwc, int64_t ldo, float* out_nchw, void* stream);
 
+/* Scheduler `.step()` on fp32 NCHW tensors (same linear form as iir_sched_step, no CFG), and
+ * a*x + b*y for add_noise (schedulers/lcm_single_step_scheduler.py:492-513; pipelines/sdxl_instantir.py:931-939). */
+int iir_sched_step_f32(const float* eps, const float* x, const float* noise, const float* coef, int64_t n, float* prev,
+                       float* x0_out, void* stream);
+int iir_axpby_f32(const float* x, const float* y, const float* coef, int64_t n, float* out, void* stream);
+
 int iir_transpose_f16(const void* in, int64_t ldi, int32_t rows, int32_t cols, void* out, int64_t ldo, int32_t rows_pad,
                       void* stream);
 int iir_abi_version(void);

@@ -218,3 +218,41 @@ extern "C" int iir_transpose_f16(const void* in, int64_t ldi, int32_t rows, int3
 }
 
 extern "C" int iir_abi_version(void) { return IIR_ABI_VERSION; }
+
+namespace {
+// Scheduler update on fp32 NCHW tensors (the scheduler objects' .step() API):
+//   x0 = (x - sb * eps) / sa ; prev = k0*x0 + k1*x + k2*eps + k3*noise ; coef = {_, sb, sa, k0, k1, k2, k3, _}
+__global__ void sched_step_f32_kernel(const float* eps, const float* x, const float* noise, const float* coef, long n,
+                                      float* prev, float* x0_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sb = coef[1], sa = coef[2], k0 = coef[3], k1 = coef[4], k2 = coef[5], k3 = coef[6];
+    const float e = eps[i], xv = x[i];
+    const float x0 = (xv - sb * e) / sa;
+    float pv = k0 * x0 + k1 * xv;
+    if (k2 != 0.f) pv = pv + k2 * e;
+    if (noise && k3 != 0.f) pv = pv + k3 * noise[i];
+    prev[i] = pv;
+    if (x0_out) x0_out[i] = x0;
+}
+// a*x + b*y elementwise fp32 (add_noise: sqrt(abar)*x + sqrt(1-abar)*noise), coef = device {a, b}
+__global__ void axpby_f32_kernel(const float* x, const float* y, const float* coef, long n, float* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = coef[0] * x[i] + coef[1] * y[i];
+}
+}  // namespace
+
+extern "C" int iir_sched_step_f32(const float* eps, const float* x, const float* noise, const float* coef, int64_t n,
+                                  float* prev, float* x0_out, void* stream) {
+    if (!eps || !x || !coef || !prev || n <= 0) return IIR_EINVAL;
+    hipLaunchKernelGGL(sched_step_f32_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, noise, coef,
+                       (long)n, prev, x0_out);
+    return iir_launch_status();
+}
+
+extern "C" int iir_axpby_f32(const float* x, const float* y, const float* coef, int64_t n, float* out, void* stream) {
+    if (!x || !y || !coef || !out || n <= 0) return IIR_EINVAL;
+    hipLaunchKernelGGL(axpby_f32_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, coef, (long)n, out);
+    return iir_launch_status();
+}

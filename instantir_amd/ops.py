@@ -210,3 +210,16 @@ def transpose(x, out, rows_pad):
     L.check(L.load().iir_transpose_f16(x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), out.stride(0), rows_pad,
                                        _stream()), "iir_transpose_f16")
     return out
+
+
+def sched_step_f32(eps, x, coef, prev, noise=None, x0_out=None):
+    """fp32 contiguous tensors of equal shape; coef fp32 device (8,)."""
+    L.check(L.load().iir_sched_step_f32(eps.data_ptr(), x.data_ptr(), _p(noise), coef.data_ptr(), x.numel(), prev.data_ptr(),
+                                        _p(x0_out), _stream()), "iir_sched_step_f32")
+    return prev
+
+
+def axpby_f32(x, y, coef, out):
+    L.check(L.load().iir_axpby_f32(x.data_ptr(), y.data_ptr(), coef.data_ptr(), x.numel(), out.data_ptr(), _stream()),
+            "iir_axpby_f32")
+    return out

@@ -1,0 +1,412 @@
+"""`InstantIRPipeline` for MI355X: the reference's pipeline API over the HIP engine.
+
+Mirrors `pipelines/sdxl_instantir.py::InstantIRPipeline` (constructor :303-348, `prepare_previewers`
+:350-397, `__call__` :1065-1739) for the denoising path: same keyword arguments and defaults, same
+error conventions for the checks it implements, same outputs.  The hot loop (:1497-1660) runs as
+HIP kernel launches, optionally replayed from a hipGraph per loop phase.
+
+Observable deviations, all documented in SURVEY.md Appendix C and DESIGN.md:
+  Q2  steps whose cond_scale is <= 0.1 everywhere run the UNet without residuals (the reference
+      multiplies the previous step's residuals by 0); on step 0 that raises a clear error instead
+      of the reference's NameError.
+  Q3  preview latents are copied to the host only when `save_preview_row=True`.
+  Q5  `multistep_restore=True` raises NotImplementedError (unusable with the shipped scheduler).
+  Q8/Q13  Resampler / embeddings hoisted out of the step.
+Latents are carried in fp32 between steps (the reference carries fp16); UNet inputs are fp16.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .config import UNetConfig
+from .engine import CPAD, F16, HipAggregator, HipUNet
+from .schedulers import DDIMScheduler, DDPMScheduler, LCMSingleStepScheduler  # noqa: F401
+from .weights import LCM_LORA_MODULES, PREVIEWER_LORA_MODULES, lora_target
+
+
+class StableDiffusionXLPipelineOutput(SimpleNamespace):
+    """`.images` like diffusers' output class (pipelines/sdxl_instantir.py:1739)."""
+
+
+class _AggregatorHandle:
+    """`pipe.aggregator.load_state_dict(sd)` / `.to(...)` surface of infer.py:142-144."""
+
+    def __init__(self, pipe):
+        self._pipe = pipe
+
+    def load_state_dict(self, sd, strict=True):
+        from .weights import aggregator_specs
+        want = {n for n, _, _ in aggregator_specs(self._pipe.cfg)}
+        missing, unexpected = sorted(want - set(sd)), sorted(set(sd) - want)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for Aggregator: missing {missing[:5]} unexpected {unexpected[:5]}")
+        self._pipe._agg_sd = dict(sd)
+        self._pipe._agg = None
+
+    def to(self, *a, **k):
+        return self
+
+
+class InstantIRPipeline:
+    vae_scale_factor = 8
+
+    def __init__(self, cfg: UNetConfig, unet_state_dict: Dict[str, torch.Tensor], aggregator_state_dict=None,
+                 scheduler=None, vae=None, device="cuda:0"):
+        """unet_state_dict: diffusers SDXL names + TA-IP processor + Resampler weights (what
+        `load_adapter_to_pipe` leaves in `pipe.unet`, module/ip_adapter/utils.py:136-161)."""
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self._unet_sd = unet_state_dict
+        self._agg_sd = aggregator_state_dict
+        self._lora = None
+        self._lora_scaling = 1.0
+        self.scheduler = scheduler if scheduler is not None else DDPMScheduler()
+        self.aggregator = _AggregatorHandle(self)
+        self.vae = vae
+        self._unet = self._unet_prev = self._agg = None
+        self._graphs = {}
+        self.use_graphs = True
+        self._guidance_scale = 7.0
+
+    # ---- reference surface ----------------------------------------------------------------------
+    def to(self, *a, **k):
+        return self
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        # pipelines/sdxl_instantir.py:1050-1051 (time_cond_proj_dim is None for SDXL)
+        return self._guidance_scale > 1
+
+    def prepare_previewers(self, lora_state_dict: Dict[str, torch.Tensor], use_lcm=False, lora_alpha=None):
+        """pipelines/sdxl_instantir.py:350-397.  `lora_state_dict` holds peft-named tensors
+        (`<module>.lora_A.weight` / `.lora_B.weight`) -- the form the reference has after
+        `convert_unet_state_dict_to_peft` and the `attn2` -> `attn2.processor` rename (:364-370).
+        Raises ValueError on keys that match no LoRA target (:390-394); missing keys are ignored."""
+        targets = LCM_LORA_MODULES if use_lcm else PREVIEWER_LORA_MODULES
+        unexpected = []
+        for k in lora_state_dict:
+            for suf in (".lora_A.weight", ".lora_B.weight"):
+                if k.endswith(suf):
+                    path = k[: -len(suf)]
+                    if not lora_target(path, targets) or (path + ".weight") not in self._unet_sd:
+                        unexpected.append(k)
+                    break
+            else:
+                unexpected.append(k)
+        if unexpected:
+            raise ValueError("Loading adapter weights from state_dict led to unexpected keys not found in the model: "
+                             f" {unexpected}. ")
+        lora_alpha = 1 if lora_alpha is None else lora_alpha
+        self._lora = dict(lora_state_dict)
+        self._lora_scaling = lora_alpha / self.cfg.lora_rank          # peft: alpha / r with r = 64 (:376-381)
+        self._unet_prev = None
+        return lora_alpha
+
+    # ---- engine construction ----------------------------------------------------------------------
+    def _build(self):
+        if self._unet is None:
+            self._unet = HipUNet(self.cfg, self._unet_sd, self.device)
+        if self._unet_prev is None and self._lora is not None:
+            self._unet_prev = HipUNet(self.cfg, self._unet_sd, self.device, lora=self._lora, lora_scaling=self._lora_scaling)
+        if self._agg is None:
+            if self._agg_sd is None:
+                raise RuntimeError("aggregator weights not loaded: call pipe.aggregator.load_state_dict(...)")
+            self._agg = HipAggregator(self.cfg, self._agg_sd, self.device)
+
+    # ---- input checks (pipelines/sdxl_instantir.py:749-864, the conditions that apply to tensor inputs) ----
+    def check_inputs(self, prompt, prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds,
+                     ip_adapter_image, ip_adapter_image_embeds, control_guidance_start, control_guidance_end,
+                     callback_on_step_end_tensor_inputs):
+        if callback_on_step_end_tensor_inputs is not None and not all(
+                k in ("latents", "prompt_embeds", "negative_prompt_embeds") for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in ['latents', 'prompt_embeds', "
+                             f"'negative_prompt_embeds'], but found {callback_on_step_end_tensor_inputs}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to"
+                             " only forward one of the two.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if prompt is not None:
+            raise NotImplementedError("text encoders are outside this build's hot path: pass `prompt_embeds` / "
+                                      "`pooled_prompt_embeds` (SURVEY.md section 8a row P3)")
+        if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but"
+                             f" got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` {negative_prompt_embeds.shape}.")
+        if prompt_embeds is not None and pooled_prompt_embeds is None:
+            raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed. Make sure to "
+                             "generate `pooled_prompt_embeds` from the same text encoder that was used to generate `prompt_embeds`.")
+        if negative_prompt_embeds is not None and negative_pooled_prompt_embeds is None:
+            raise ValueError("If `negative_prompt_embeds` are provided, `negative_pooled_prompt_embeds` also have to be passed.")
+        for s, e in [(control_guidance_start, control_guidance_end)]:
+            if s >= e:
+                raise ValueError(f"control guidance start: {s} cannot be larger or equal to control guidance end: {e}.")
+            if s < 0.0:
+                raise ValueError(f"control guidance start: {s} can't be smaller than 0.")
+            if e > 1.0:
+                raise ValueError(f"control guidance end: {e} can't be larger than 1.0.")
+        if ip_adapter_image is not None and ip_adapter_image_embeds is not None:
+            raise ValueError("Provide either `ip_adapter_image` or `ip_adapter_image_embeds`. Cannot leave both "
+                             "`ip_adapter_image` and `ip_adapter_image_embeds` defined.")
+        if ip_adapter_image_embeds is not None:
+            if not isinstance(ip_adapter_image_embeds, list):
+                raise ValueError(f"`ip_adapter_image_embeds` has to be of type `list` but is {type(ip_adapter_image_embeds)}")
+            if ip_adapter_image_embeds[0].ndim not in [3, 4]:
+                raise ValueError("`ip_adapter_image_embeds` has to be a list of 3D or 4D tensors but is "
+                                 f"{ip_adapter_image_embeds[0].ndim}D")
+
+    # ---- the call ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt=None, prompt_2=None, image=None, height=None, width=None, num_inference_steps: int = 30,
+                 timesteps: List[int] = None, denoising_end: Optional[float] = None, guidance_scale: float = 7.0,
+                 negative_prompt=None, negative_prompt_2=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0,
+                 generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
+                 negative_pooled_prompt_embeds=None, ip_adapter_image=None, ip_adapter_image_embeds=None,
+                 output_type: Optional[str] = "pil", return_dict: bool = True, save_preview_row: bool = False,
+                 init_latents_with_lq: bool = True, multistep_restore: bool = False, adastep_restore: bool = False,
+                 cross_attention_kwargs=None, guidance_rescale: float = 0.0, controlnet_conditioning_scale=1.0,
+                 control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, preview_start: float = 0.0,
+                 preview_end: float = 1.0, original_size=None, crops_coords_top_left=(0, 0), target_size=None,
+                 negative_original_size=None, negative_crops_coords_top_left=(0, 0), negative_target_size=None,
+                 clip_skip=None, callback_on_step_end: Optional[Callable] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], previewer_scheduler=None,
+                 reference_latents=None, init_noise=None, step_noises=None, **kwargs):
+        """Keyword arguments and defaults of pipelines/sdxl_instantir.py:1067-1115.  Two additions for
+        bit-reproducible parity runs: `init_noise` (the randn of init_latents) and
+        `step_noises` (list of per-step DDPM noises) replace draws from `generator` when given.
+        `image` must be the LQ *latent* (B,4,h,w) here unless a VAE is attached (`image.shape[1] == 4` branch of :1369-1382)."""
+        if multistep_restore:
+            raise NotImplementedError("multistep_restore passes kwargs the shipped DDPM scheduler does not accept "
+                                      "(SURVEY.md Appendix C Q5)")
+        if guidance_rescale and guidance_rescale > 0.0:
+            raise NotImplementedError("guidance_rescale > 0 is not on the benchmarked path (default 0.0)")
+        self.check_inputs(prompt, prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds,
+                          ip_adapter_image, ip_adapter_image_embeds, control_guidance_start, control_guidance_end,
+                          callback_on_step_end_tensor_inputs)
+        self._guidance_scale = guidance_scale
+        cfg, dev = self.cfg, self.device
+        do_cfg = self.do_classifier_free_guidance
+        self._build()
+
+        B = prompt_embeds.shape[0] * num_images_per_prompt
+        assert B == len(image) or len(image) == 1                                 # :1316-1319
+        if image.shape[1] != 4:
+            if self.vae is None:
+                raise NotImplementedError("pixel-space `image` needs a VAE; pass the LQ latent (B,4,h,w)")
+            image = self.vae.encode_to_latent(image)
+        lq = image.to(dev, torch.float32)
+        if lq.shape[0] == 1 and B > 1:
+            lq = lq.repeat(B, 1, 1, 1)
+        lq = lq.contiguous()
+        Hl, Wl = lq.shape[2], lq.shape[3]
+        height, width = Hl * self.vae_scale_factor, Wl * self.vae_scale_factor
+
+        # -- embeddings, CFG order [negative; positive] (:1456-1464)
+        if do_cfg:
+            if negative_prompt_embeds is None:
+                negative_prompt_embeds = torch.zeros_like(prompt_embeds)           # force_zeros_for_empty_prompt
+                negative_pooled_prompt_embeds = torch.zeros_like(pooled_prompt_embeds)
+            ctx = torch.cat([negative_prompt_embeds, prompt_embeds], 0)
+            pooled = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], 0)
+        else:
+            ctx, pooled = prompt_embeds, pooled_prompt_embeds
+        rep = 2 if do_cfg else 1
+        R = rep * B
+        original_size = original_size or (height, width)
+        target_size = target_size or (height, width)
+        ids = list(original_size) + list(crops_coords_top_left) + list(target_size)     # :965-981
+        if cfg.addition_time_embed_dim * len(ids) + cfg.pooled_dim != cfg.add_embed_in:
+            raise ValueError("Model expects an added time embedding vector of length "
+                             f"{cfg.add_embed_in}, but a vector of {cfg.addition_time_embed_dim * len(ids) + cfg.pooled_dim} was created.")
+        time_ids = torch.tensor([ids], dtype=torch.float32).repeat(R, 1)
+        if ip_adapter_image_embeds is None:
+            raise NotImplementedError("pass `ip_adapter_image_embeds` (DINOv2 features); the image encoder is outside this build")
+        img = ip_adapter_image_embeds[0]
+        if do_cfg:                                                                  # :709-722
+            neg, pos = img.chunk(2)
+            img = torch.cat([neg.repeat(num_images_per_prompt, *([1] * (neg.dim() - 1))),
+                             pos.repeat(num_images_per_prompt, *([1] * (pos.dim() - 1)))])
+
+        # -- timetable and gates (:1385, :1415-1425)
+        self.scheduler.set_timesteps(num_inference_steps, device=None, **({"timesteps": timesteps} if timesteps else {}))
+        ts = [int(t) for t in self.scheduler.timesteps]
+        n = len(ts)
+        keep, previewing = [], []
+        for i in range(n):
+            keep.append(1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end))
+            previewing.append(1.0 - float(i / n < preview_start or (i + 1) / n > preview_end))
+        if isinstance(controlnet_conditioning_scale, list):
+            assert len(controlnet_conditioning_scale) == n, \
+                f"{len(controlnet_conditioning_scale)} controlnet scales do not match number of sampling steps {n}"
+            ccs = controlnet_conditioning_scale
+        else:
+            ccs = [controlnet_conditioning_scale] * n
+        if denoising_end is not None and isinstance(denoising_end, float) and 0 < denoising_end < 1:      # :1470-1483
+            cutoff = int(round(self.scheduler.config.num_train_timesteps - denoising_end * self.scheduler.config.num_train_timesteps))
+            ts = [t for t in ts if t >= cutoff]
+
+        # -- step-invariant device state
+        st = self._unet.prepare(ctx, pooled, time_ids, self._unet.resampler(img), Hl, Wl)
+        st_prev = None
+        if self._unet_prev is not None:
+            st_prev = self._unet_prev.prepare(ctx, pooled, time_ids, self._unet_prev.resampler(img), Hl, Wl)
+        st_agg = self._agg.prepare(pooled, time_ids, Hl, Wl)
+
+        # -- initial latents (:1388-1403)
+        if init_latents_with_lq:
+            if init_noise is None:
+                gdev = generator.device if generator is not None else dev
+                init_noise = torch.randn(lq.shape, generator=generator, device=gdev, dtype=torch.float32)
+            x = self.scheduler.add_noise(lq, init_noise.to(dev, torch.float32), torch.tensor([ts[0]] * B))
+        else:
+            if latents is None:
+                gdev = generator.device if generator is not None else dev
+                latents = torch.randn(lq.shape, generator=generator, device=gdev, dtype=torch.float32)
+            x = latents.to(dev, torch.float32) * self.scheduler.init_noise_sigma
+        x = x.contiguous()
+
+        loop = _DenoiseLoop(self, B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler)
+        preview_row = []
+        preview_factor = torch.ones(B)
+        for i, t in enumerate(ts):
+            scale_rows = torch.clamp(preview_factor, 0.0, ccs[i]) * keep[i]            # :1538-1540
+            use_agg = bool((scale_rows > 0.1).sum().item() > 0)                      # :1542
+            mode = "unet"
+            if use_agg:
+                mode = "preview" if (previewing[i] > 0 and st_prev is not None and previewer_scheduler is not None) else "agg"
+                if previewing[i] > 0 and (st_prev is None or previewer_scheduler is None):
+                    raise RuntimeError("previewing requested but no previewer: call prepare_previewers(...) and pass "
+                                       "previewer_scheduler=LCMSingleStepScheduler")
+            elif i == 0:
+                raise RuntimeError("control_guidance_start > 0 leaves no aggregator residuals for step 0 "
+                                   "(the reference fails with NameError here, SURVEY.md Appendix C Q2)")
+            noise = None
+            if step_noises is not None:
+                noise = step_noises[i]
+            x0 = loop.step(mode, t, x, scale_rows.repeat(rep), guidance_scale, eta, noise, generator,
+                           want_x0=adastep_restore, want_preview=save_preview_row or adastep_restore)
+            if mode == "preview" and save_preview_row:
+                preview_row.append(loop.preview_f32[B * (rep - 1):].clone().cpu())
+            if adastep_restore:                                                    # :1636-1644
+                pv = loop.preview_f32[B * (rep - 1):].float() if mode == "preview" else lq
+                pred_x0_l2 = (pv - x0).pow(2).sum(dim=(1, 2, 3))
+                prev_l2 = (pv - loop.previewer_mean).pow(2).sum(dim=(1, 2, 3))
+                loop.previewer_mean = pv.clone()
+                preview_factor = (pred_x0_l2 / prev_l2).cpu()
+            if callback_on_step_end is not None:
+                cb = callback_on_step_end(self, i, t, {"latents": x})
+                x = cb.pop("latents", x)
+        latents_out = x
+        if output_type == "latent":
+            image_out = latents_out
+        else:
+            if self.vae is None:
+                raise NotImplementedError("output_type other than 'latent' needs a VAE attached to the pipeline")
+            image_out = self.vae.decode_latent(latents_out, output_type)
+        if not return_dict:
+            return (image_out, preview_row) if save_preview_row else (image_out,)
+        return StableDiffusionXLPipelineOutput(images=image_out)
+
+
+class _DenoiseLoop:
+    """Device buffers + (optionally hipGraph-captured) launch sequences of one denoising step.
+    Three phases exist (pipelines/sdxl_instantir.py:1542-1616): "preview" (UNet+LoRA -> LCM preview
+    -> Aggregator -> UNet), "agg" (Aggregator on the LQ / reference latent -> UNet), "unet"."""
+
+    def __init__(self, pipe, B, rep, H, W, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler):
+        dev = pipe.device
+        self.p, self.B, self.rep, self.H, self.W = pipe, B, rep, H, W
+        self.st, self.st_prev, self.st_agg = st, st_prev, st_agg
+        self.prev_sched = previewer_scheduler
+        R, HW = B * rep, H * W
+        self.lat16 = torch.zeros(R * HW, CPAD, dtype=F16, device=dev)
+        self.prev16 = torch.zeros(R * HW, CPAD, dtype=F16, device=dev)
+        self.lq16 = torch.zeros(R * HW, CPAD, dtype=F16, device=dev)
+        ops.pack_latent(lq, self.lq16, rep=rep)
+        self.ref16 = None
+        if reference_latents is not None:
+            self.ref16 = torch.zeros(R * HW, CPAD, dtype=F16, device=dev)
+            ops.pack_latent(reference_latents.to(dev, torch.float32).contiguous(), self.ref16, rep=rep)
+        self.x_in = torch.empty(B, 4, H, W, dtype=torch.float32, device=dev)
+        self.x_out = torch.empty_like(self.x_in)
+        self.x0 = torch.empty_like(self.x_in)
+        self.noise = torch.zeros_like(self.x_in)
+        self.preview_f32 = torch.zeros(R, 4, H, W, dtype=torch.float32, device=dev)
+        self.previewer_mean = torch.zeros_like(self.x_in)
+        # per-step scalars: [t x R | lcm coef x4 | sched coef x8 | res scale x R]
+        self.n_sc = R + 4 + 8 + R
+        # ring of pinned staging rows: a row is rewritten only after the H2D copy that read it has completed
+        self.sc_ring = [torch.zeros(self.n_sc, dtype=torch.float32).pin_memory() for _ in range(8)]
+        self.sc_events = [None] * 8
+        self.sc_idx = 0
+        self.sc_dev = torch.zeros(self.n_sc, dtype=torch.float32, device=dev)
+        self.t_dev = self.sc_dev[:R].view(R, 1)
+        self.lcm_coef = self.sc_dev[R:R + 4]
+        self.sched_coef = self.sc_dev[R + 4:R + 12]
+        self.res_scale = self.sc_dev[R + 12:]
+        self.graphs = {}
+
+    def _launch(self, mode, use_noise, want_x0, want_preview):
+        p, B, rep = self.p, self.B, self.rep
+        ops.pack_latent(self.x_in, self.lat16, rep=rep)                      # cat([latents]*2), :1503
+        down = mid = None
+        if mode != "unet":
+            if mode == "preview":
+                eps1 = p._unet_prev.forward(self.lat16, self.t_dev, self.st_prev)          # :1545-1554
+                ops.lcm_step(eps1, B, rep, self.lcm_coef, self.x_in, self.prev16,
+                             self.preview_f32 if want_preview else None)                 # :1555-1561
+                cond = self.prev16
+            else:
+                cond = self.ref16 if self.ref16 is not None else self.lq16               # :1579-1582
+            down, mid = p._agg.forward(self.lq16, cond, self.t_dev, self.st_agg)           # :1591-1599
+        eps = p._unet.forward(self.lat16, self.t_dev, self.st, down, mid, self.res_scale if down is not None else None)
+        ops.sched_step(eps, B, self.sched_coef, self.x_in, self.x_out, noise=self.noise if use_noise else None,
+                       cfg=rep == 2, x0_out=self.x0 if want_x0 else None)                 # :1619-1633
+
+    def step(self, mode, t, x, res_scale_rows, guidance, eta, noise, generator, want_x0=False, want_preview=False):
+        p, R = self.p, self.B * self.rep
+        slot = self.sc_idx % len(self.sc_ring)
+        self.sc_idx += 1
+        if self.sc_events[slot] is not None:
+            self.sc_events[slot].synchronize()
+        sc = self.sc_ring[slot]
+        sc[:R] = float(t)
+        if mode == "preview":
+            sc[R:R + 4] = torch.tensor(self.prev_sched.preview_coefficients(t))
+        coef = p.scheduler.step_coefficients(t, eta=eta)
+        coef[0] = float(guidance)
+        sc[R + 4:R + 12] = torch.tensor(coef)
+        sc[R + 12:] = res_scale_rows.float()
+        use_noise = coef[6] != 0.0
+        if use_noise:
+            if noise is None:
+                gdev = generator.device if generator is not None else self.x_in.device
+                noise = torch.randn(self.x_in.shape, generator=generator, device=gdev, dtype=torch.float32)
+            self.noise.copy_(noise.to(self.noise.device, torch.float32), non_blocking=True)
+        self.sc_dev.copy_(sc, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.sc_events[slot] = ev
+        self.x_in.copy_(x)
+        key = (mode, use_noise, want_x0, want_preview)
+        if p.use_graphs:
+            g = self.graphs.get(key)
+            if g is None:
+                self._launch(*key)                        # warm-up: one-time attribute / workspace setup
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch(*key)
+                self.graphs[key] = g
+            g.replay()
+        else:
+            self._launch(*key)
+        x.copy_(self.x_out)
+        return self.x0 if want_x0 else None

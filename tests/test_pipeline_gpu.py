@@ -1,0 +1,117 @@
+"""GPU parity of the whole denoising loop (InstantIRPipeline over HIP) against the CPU oracle loop,
+tiny geometry, identical seeded weights / inputs / noises.  Tolerance: latent PSNR (BASELINE.json
+north_star asks >= 50 dB vs the reference latents at fp16)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def psnr(got, want):
+    mse = ((got - want) ** 2).mean().item()
+    peak = want.abs().max().item()
+    return 10 * math.log10(peak * peak / max(mse, 1e-30))
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from instantir_amd import lib, weights as W
+    from instantir_amd.config import UNetConfig
+    lib.load()
+    cfg = UNetConfig.tiny()
+    sd = W.synth_state_dict(W.unet_specs(cfg), 11)
+    sda = W.synth_state_dict(W.aggregator_specs(cfg), 12)
+    lora = W.synth_state_dict(W.lora_specs(cfg), 13)
+    g = torch.Generator().manual_seed(42)
+    B, H = 2, 16
+    inp = dict(
+        B=B, H=H,
+        lq=torch.randn(B, 4, H, H, generator=g) * 0.8,
+        pe=torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g).half().float(),
+        pooled=torch.randn(B, cfg.pooled_dim, generator=g).half().float(),
+        npe=torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g).half().float(),
+        npooled=torch.randn(B, cfg.pooled_dim, generator=g).half().float(),
+        img=torch.randn(2, B, cfg.resampler.seq_len, cfg.resampler.embedding_dim, generator=g).half().float(),
+        init_noise=torch.randn(B, 4, H, H, generator=g),
+        noises=[torch.randn(B, 4, H, H, generator=g) for _ in range(8)],
+    )
+    return cfg, sd, sda, lora, inp
+
+
+def _oracle(cfg, sd, sda, lora, inp, **kw):
+    from oracle import pipeline as OP
+    P = {k: v.float() for k, v in sd.items()}
+    PA = {k: v.float() for k, v in sda.items()}
+    L = {k: v.float() for k, v in lora.items()}
+    L["scaling"] = 16.0 / cfg.lora_rank
+    return OP.denoise(P, PA, L, cfg, inp["lq"], inp["pe"], inp["pooled"], inp["img"], negative_prompt_embeds=inp["npe"],
+                      negative_pooled=inp["npooled"], init_noise=inp["init_noise"], **kw)
+
+
+def _pipe(cfg, sd, sda, lora, sched):
+    from instantir_amd.pipeline import InstantIRPipeline
+    pipe = InstantIRPipeline(cfg, sd, scheduler=sched)
+    pipe.aggregator.load_state_dict(sda)
+    pipe.prepare_previewers(lora, lora_alpha=16)
+    return pipe
+
+
+def _call(pipe, inp, **kw):
+    from instantir_amd.schedulers import LCMSingleStepScheduler
+    lcm = LCMSingleStepScheduler.from_config(pipe.scheduler.config)
+    return pipe(image=inp["lq"], prompt_embeds=inp["pe"], pooled_prompt_embeds=inp["pooled"],
+                negative_prompt_embeds=inp["npe"], negative_pooled_prompt_embeds=inp["npooled"],
+                ip_adapter_image_embeds=[inp["img"]], output_type="latent", previewer_scheduler=lcm,
+                init_noise=inp["init_noise"], **kw).images.float().cpu()
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_ddim_cfg_loop(env, graphs):
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    want = _oracle(cfg, sd, sda, lora, inp, num_inference_steps=6, guidance_scale=7.0, sampler="ddim")
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    pipe.use_graphs = graphs
+    got = _call(pipe, inp, num_inference_steps=6, guidance_scale=7.0)
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p >= 40, p
+
+
+def test_ddpm_phases_loop(env):
+    """DDPM with explicit noises, preview_start / control_guidance_end gates: all three loop phases."""
+    from instantir_amd.schedulers import DDPMScheduler
+    cfg, sd, sda, lora, inp = env
+    kw = dict(num_inference_steps=8, guidance_scale=5.0, preview_start=0.25, control_guidance_end=0.75)
+    want = _oracle(cfg, sd, sda, lora, inp, sampler="ddpm", step_noises=inp["noises"], **kw)
+    pipe = _pipe(cfg, sd, sda, lora, DDPMScheduler())
+    got = _call(pipe, inp, step_noises=inp["noises"], **kw)
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p >= 40, p
+
+
+def test_no_cfg_single_image(env):
+    """BASELINE config 1 shape of the control flow: cfg = 1.0 (no CFG doubling), 4 steps."""
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    one = {k: (v[:1] if torch.is_tensor(v) and v.shape[0] == inp["B"] else v) for k, v in inp.items()}
+    one["img"] = inp["img"][1:, :1]
+    one["B"] = 1
+    from oracle import pipeline as OP
+    P = {k: v.float() for k, v in sd.items()}
+    PA = {k: v.float() for k, v in sda.items()}
+    L = {k: v.float() for k, v in lora.items()}
+    L["scaling"] = 16.0 / cfg.lora_rank
+    want = OP.denoise(P, PA, L, cfg, one["lq"], one["pe"], one["pooled"], one["img"], init_noise=one["init_noise"],
+                      num_inference_steps=4, guidance_scale=1.0, sampler="ddim")
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    from instantir_amd.schedulers import LCMSingleStepScheduler
+    got = pipe(image=one["lq"], prompt_embeds=one["pe"], pooled_prompt_embeds=one["pooled"],
+               ip_adapter_image_embeds=[one["img"]], output_type="latent", num_inference_steps=4, guidance_scale=1.0,
+               previewer_scheduler=LCMSingleStepScheduler.from_config(pipe.scheduler.config),
+               init_noise=one["init_noise"]).images.float().cpu()
+    p = psnr(got, want)
+    assert p >= 40, p
