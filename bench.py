@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the InstantIR denoising step on MI355X (BASELINE.json metric: denoising steps/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): one 1024x1024 image
+per GPU (latent 128x128), classifier-free guidance 7.0 (2 UNet rows), full SDXL-base UNet with TA-IP
+adapters, previewer-LoRA UNet + LCM preview + Aggregator + UNet every step (preview_start = 0), DDIM
+(eta 0) update, fp16 storage / fp32 accumulate, seeded synthetic weights of the exact shapes (no
+checkpoints exist offline).  A "step" is one iteration of pipelines/sdxl_instantir.py:1497 for the
+GPU's local image.  Multi-GPU: images shard across ranks, no per-step collective ("weak" scaling);
+weights are broadcast once from rank 0 over RCCL before the timed region.
+
+Timed region: K steps replayed from the captured hipGraph of the step, inputs resident in HBM,
+bracketed by barrier + synchronize; max over ranks; value = N*K / time.
+roofline: a separate, eager pass of 2 steps where every MFMA-kernel launch is bracketed by HIP
+events on its stream; the kernel class with the largest total time is reported against the dense
+fp16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).  Algorithmic FLOPs per launch = 2*M*N*K (GEMM /
+implicit-GEMM conv) or 4*B*h*Tq*Tkv*64 (attention).
+cpu_baseline: the CPU fp32 oracle (oracle/, kind "port") timed on the host cores for a bounded sample
+(one UNet forward of one row at the same resolution), converted with SURVEY.md section 8d's FLOP model.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch
+
+UNET_TFLOP_ROW = 6.833     # SURVEY.md section 8d, 1024^2
+STEP_TFLOP = 39.74         # 2 * (2 * UNet + Aggregator) per image with CFG
+
+
+def host_cores():
+    """CPU share of this process: min(affinity, cgroup v2 quota).  The GPU boxes expose 256 logical
+    CPUs but a 16-CPU quota; oversubscribing the quota stalls torch's thread pool."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=1024, help="image side (pixels)")
+    ap.add_argument("--tiny", action="store_true", help="tiny geometry (debug only, not a valid bench)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    from instantir_amd import lib, ops, parallel, weights as W
+    from instantir_amd.config import UNetConfig
+    from instantir_amd.pipeline import InstantIRPipeline, _DenoiseLoop
+    from instantir_amd.schedulers import DDIMScheduler, LCMSingleStepScheduler
+
+    rank, world, local, dev = parallel.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the denoising path has no CPU fallback")
+    lib.load()
+    cfg = UNetConfig.tiny() if args.tiny else UNetConfig.sdxl()
+    Hl = args.size // 8
+    B, guidance, n_steps_sched = 1, 7.0, 30
+
+    log(f"rank {rank}/{world} on {dev}: generating weights")
+    # ---- frozen weights: rank 0 generates, everyone receives them over RCCL -----------------------
+    t0 = time.time()
+    seed = 1234
+    sd = W.synth_state_dict(W.unet_specs(cfg), seed, device=dev)
+    sda = W.synth_state_dict(W.aggregator_specs(cfg), seed + 1, device=dev)
+    lora = W.synth_state_dict(W.lora_specs(cfg), seed + 2, device=dev)
+    if world > 1:
+        for d in (sd, sda, lora):
+            parallel.broadcast_state_dict(d, 0)
+    pipe = InstantIRPipeline(cfg, sd, scheduler=DDIMScheduler(), device=dev)
+    pipe.aggregator.load_state_dict(sda)
+    pipe.prepare_previewers(lora, lora_alpha=cfg.lora_rank // 8)
+    pipe.use_graphs = not args.no_graph
+    pipe._build()
+    log(f"engines built ({time.time() - t0:.1f} s)")
+    n_params = sum(v.numel() for v in sd.values()) + sum(v.numel() for v in sda.values())
+    cpu_sd = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_sd = {k: v.float().cpu() for k, v in sd.items()}
+    del sd, sda, lora
+    pipe._unet_sd = pipe._agg_sd = pipe._lora = None
+    torch.cuda.empty_cache()
+
+    # ---- synthetic inputs (seed 42 + rank: every rank restores a different image) -----------------
+    g = torch.Generator().manual_seed(42 + rank)
+    lq = torch.randn(B, 4, Hl, Hl, generator=g) * 0.8
+    pe = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g)
+    npe = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g)
+    pooled, npooled = torch.randn(B, cfg.pooled_dim, generator=g), torch.randn(B, cfg.pooled_dim, generator=g)
+    img = torch.randn(2, B, cfg.resampler.seq_len, cfg.resampler.embedding_dim, generator=g)
+    ctx, pl = torch.cat([npe, pe]), torch.cat([npooled, pooled])
+    px = Hl * 8
+    time_ids = torch.tensor([[px, px, 0, 0, px, px]], dtype=torch.float32).repeat(2 * B, 1)
+    st = pipe._unet.prepare(ctx, pl, time_ids, pipe._unet.resampler(img), Hl, Hl)
+    st_prev = pipe._unet_prev.prepare(ctx, pl, time_ids, pipe._unet_prev.resampler(img), Hl, Hl)
+    st_agg = pipe._agg.prepare(pl, time_ids, Hl, Hl)
+    lcm = LCMSingleStepScheduler.from_config(pipe.scheduler.config)
+    pipe.scheduler.set_timesteps(n_steps_sched)
+    ts = [int(t) for t in pipe.scheduler.timesteps]
+    lqd = lq.to(dev)
+    loop = _DenoiseLoop(pipe, B, 2, Hl, Hl, st, st_prev, st_agg, lqd, None, lcm)
+    x = pipe.scheduler.add_noise(lqd, torch.randn(lq.shape, generator=g).to(dev), torch.tensor([ts[0]] * B)).contiguous()
+    scale_rows = torch.ones(2 * B)
+    setup_s = time.time() - t0
+    log(f"prepared ({setup_s:.1f} s); warmup")
+
+    def run(k, start=0):
+        for i in range(k):
+            loop.step("preview", ts[(start + i) % len(ts)], x, scale_rows, guidance, 0.0, None, None)
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    log("warmup done; timing")
+    parallel.barrier()
+    t1 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t1, dev)
+    finite = bool(torch.isfinite(x).all().item())
+    log(f"timed: {dt / args.steps * 1e3:.2f} ms/step")
+
+    # ---- roofline leg: eager, every MFMA launch bracketed by HIP events --------------------------
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        pipe.use_graphs = False
+        run(1)
+        ops.PROFILER = ops.LaunchProfiler()
+        run(2)
+        summ = ops.PROFILER.summary()
+        ops.PROFILER = None
+        pipe.use_graphs = not args.no_graph
+        name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = d["ms"] / d["launches"]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(ach / 2500.0, 4), "traffic": None, "launches_per_step": d["launches"] // 2,
+                "avg_launch_us": round(avg_ms * 1e3, 2),
+                "classes": {k: {"launches_per_step": v["launches"] // 2, "ms_per_step": round(v["ms"] / 2, 3),
+                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in sorted(summ.items())}}
+
+    # ---- CPU baseline leg (rank 0 only): oracle UNet forward, 1 row ------------------------------
+    cpu = None
+    if rank == 0 and cpu_sd is not None:
+        from oracle import nets
+        ncores = host_cores()
+        log(f"cpu baseline on {ncores} cores")
+        torch.set_num_threads(ncores)
+        with torch.no_grad():
+            ip = nets.image_projection(cpu_sd, [img[1:].float()], cfg.resampler)[0]
+            tc = time.perf_counter()
+            nets.unet_forward(cpu_sd, cfg, lq, ts[0], pe, pooled, time_ids[:1], ip)
+            cpu_t = time.perf_counter() - tc
+        frac = UNET_TFLOP_ROW / STEP_TFLOP if not args.tiny else 1.0
+        cpu = {"value": round(frac / cpu_t, 5), "unit": "steps/s", "cores": ncores, "kind": "port",
+               "sample": f"oracle UNet forward, 1 row, {args.size}x{args.size}, fp32, {cpu_t:.1f} s = {frac:.3f} of a CFG step "
+                         f"by SURVEY 8d FLOPs ({UNET_TFLOP_ROW}/{STEP_TFLOP} TFLOP)"}
+
+    if rank == 0:
+        out = {
+            "metric": "denoising steps/sec at 1024x1024 (InstantIR step: previewer UNet + LCM + Aggregator + UNet, CFG)",
+            "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 (fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.size}x{args.size}, batch 1/GPU, cfg 7.0 (2 rows), 30-step DDIM "
+                                   f"timetable, preview_start 0, full SDXL+TA-IP UNet x2 + Aggregator per step"
+                                   + (" [TINY DEBUG GEOMETRY]" if args.tiny else ""),
+                       "images_per_gpu": B, "latent": [Hl, Hl], "params": n_params, "graph": not args.no_graph,
+                       "step_tflop_model": STEP_TFLOP, "model_tflops_per_gpu": round(STEP_TFLOP * args.steps / dt, 1),
+                       "images_per_s_30step_est": round(world * args.steps / dt / 30, 4), "finite": finite,
+                       "setup_s": round(setup_s, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
 }  // namespace
 
 extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
+    (void)hipGetLastError();
     if (!a || !a->Q || !a->O || a->nseg < 1 || a->nseg > 2) return IIR_EINVAL;
     if (a->Tq <= 0 || a->heads <= 0 || a->batch <= 0) return IIR_EINVAL;
     if (a->ldq % 8 || a->ldo % 4) return IIR_EINVAL;

@@ -258,6 +258,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
 }  // namespace
 
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
+    (void)hipGetLastError();
     if (!d || !d->A || !d->W || !d->C) return IIR_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % BK) return IIR_EINVAL;
     if (d->N % 4 || d->lda % 8 || d->ldc % 4) return IIR_EINVAL;
@@ -274,6 +275,7 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
 }
 
 extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
+    (void)hipGetLastError();
     if (!c || !c->X || !c->Wt || !c->Y || !c->zero_page) return IIR_EINVAL;
     if (c->ksize != 3 && c->ksize != 1) return IIR_EINVAL;
     if (c->Cin % BK || c->ldx % 8 || c->Cout % 4 || c->ldy % 4) return IIR_EINVAL;

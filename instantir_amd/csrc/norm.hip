@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* X, long ldx, f16* Y,
 extern "C" int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
                                       int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
                                       void* workspace, int64_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
     if (!X || !Y || !gamma || !beta || !workspace) return IIR_EINVAL;
     if (C % 8 || C > GN_MAXC || groups <= 0 || groups > 64 || C % groups || ldx % 8 || ldy % 8) return IIR_EINVAL;
     if (R <= 0 || HW <= 0) return IIR_EINVAL;
@@ -199,6 +200,7 @@ extern "C" int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups) { re
 extern "C" int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t rows, int32_t C, const void* gamma,
                                  const void* beta, float eps, const void* shift, const void* scale, int64_t ldmod,
                                  int32_t rows_per_mod, int32_t transposed, int32_t tr_rows, int64_t tr_bstride, void* stream) {
+    (void)hipGetLastError();
     if (!X || !Y || rows <= 0 || C % 8 || C > GN_MAXC || ldx % 8) return IIR_EINVAL;
     if ((shift == nullptr) != (scale == nullptr)) return IIR_EINVAL;
     if (shift && (rows_per_mod <= 0 || ldmod % 8)) return IIR_EINVAL;

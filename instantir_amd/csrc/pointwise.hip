@@ -153,6 +153,7 @@ inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
 
 extern "C" int iir_sinusoid_f16(const float* vals, int32_t n_vals, int32_t rows, int32_t dim, void* out, int64_t ldo,
                                 int32_t col_off, void* stream) {
+    (void)hipGetLastError();
     if (!vals || !out || n_vals <= 0 || rows <= 0 || dim <= 0 || dim % 2) return IIR_EINVAL;
     const int total = rows * n_vals * (dim / 2);
     hipLaunchKernelGGL(sinusoid_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, vals, n_vals, rows, dim,
@@ -161,6 +162,7 @@ extern "C" int iir_sinusoid_f16(const float* vals, int32_t n_vals, int32_t rows,
 }
 
 extern "C" int iir_silu_f16(const void* x, void* y, int64_t n, void* stream) {
+    (void)hipGetLastError();
     if (!x || !y || n <= 0 || n % 8) return IIR_EINVAL;
     hipLaunchKernelGGL(silu_kernel, dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, n / 8);
     return iir_launch_status();
@@ -168,6 +170,7 @@ extern "C" int iir_silu_f16(const void* x, void* y, int64_t n, void* stream) {
 
 extern "C" int iir_copy_add_f16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t dst_off, int64_t M, int32_t C,
                                 const void* add, int64_t lda, const float* add_scale, int32_t rows_per_scale, void* stream) {
+    (void)hipGetLastError();
     if (!src || !dst || M <= 0 || C <= 0 || C % 8 || lds % 8 || ldd % 8 || dst_off % 8) return IIR_EINVAL;
     if (add && (lda % 8)) return IIR_EINVAL;
     if (add_scale && rows_per_scale <= 0) return IIR_EINVAL;
@@ -179,6 +182,7 @@ extern "C" int iir_copy_add_f16(const void* src, int64_t lds, void* dst, int64_t
 
 extern "C" int iir_pack_latent(const float* x, int32_t B, int32_t C, int32_t HW, void* out, int64_t ldo, int32_t rep,
                                float scale, void* stream) {
+    (void)hipGetLastError();
     if (!x || !out || B <= 0 || C <= 0 || HW <= 0 || rep <= 0 || ldo < C) return IIR_EINVAL;
     hipLaunchKernelGGL(pack_latent_kernel, dim3(nblk((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, B, C, HW,
                        (f16*)out, (long)ldo, rep, scale);
@@ -186,6 +190,7 @@ extern "C" int iir_pack_latent(const float* x, int32_t B, int32_t C, int32_t HW,
 }
 
 extern "C" int iir_unpack_latent(const void* in, int64_t ldi, int32_t R, int32_t C, int32_t HW, float* out, void* stream) {
+    (void)hipGetLastError();
     if (!in || !out || R <= 0 || C <= 0 || HW <= 0 || ldi < C) return IIR_EINVAL;
     hipLaunchKernelGGL(unpack_latent_kernel, dim3(nblk((long)R * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)in,
                        (long)ldi, R, C, HW, out);
@@ -195,6 +200,7 @@ extern "C" int iir_unpack_latent(const void* in, int64_t ldi, int32_t R, int32_t
 extern "C" int iir_sched_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int32_t HW, int32_t cfg,
                               const float* coef, const float* x, const float* noise, float* prev, float* x0_out,
                               float* eps_out, void* stream) {
+    (void)hipGetLastError();
     if (!eps_nhwc || !coef || !x || !prev || B <= 0 || C <= 0 || HW <= 0 || lde < C) return IIR_EINVAL;
     hipLaunchKernelGGL(sched_step_kernel, dim3(nblk((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const f16*)eps_nhwc, (long)lde, B, C, HW, cfg, coef, x, noise, prev, x0_out, eps_out);
@@ -203,6 +209,7 @@ extern "C" int iir_sched_step(const void* eps_nhwc, int64_t lde, int32_t B, int3
 
 extern "C" int iir_lcm_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t rep, int32_t C, int32_t HW,
                             const float* coef, const float* x, void* out_nhwc, int64_t ldo, float* out_nchw, void* stream) {
+    (void)hipGetLastError();
     if (!eps_nhwc || !coef || !x || !out_nhwc || B <= 0 || rep <= 0 || C <= 0 || HW <= 0 || lde < C || ldo < C) return IIR_EINVAL;
     hipLaunchKernelGGL(lcm_step_kernel, dim3(nblk((long)B * rep * HW, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const f16*)eps_nhwc, (long)lde, B, rep, C, HW, coef, x, (f16*)out_nhwc, (long)ldo, out_nchw);
@@ -211,6 +218,7 @@ extern "C" int iir_lcm_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_
 
 extern "C" int iir_transpose_f16(const void* in, int64_t ldi, int32_t rows, int32_t cols, void* out, int64_t ldo,
                                  int32_t rows_pad, void* stream) {
+    (void)hipGetLastError();
     if (!in || !out || rows <= 0 || cols <= 0 || rows_pad < rows || ldo < rows_pad) return IIR_EINVAL;
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows_pad + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream,
                        (const f16*)in, (long)ldi, rows, cols, (f16*)out, (long)ldo, rows_pad);
@@ -245,6 +253,7 @@ __global__ void axpby_f32_kernel(const float* x, const float* y, const float* co
 
 extern "C" int iir_sched_step_f32(const float* eps, const float* x, const float* noise, const float* coef, int64_t n,
                                   float* prev, float* x0_out, void* stream) {
+    (void)hipGetLastError();
     if (!eps || !x || !coef || !prev || n <= 0) return IIR_EINVAL;
     hipLaunchKernelGGL(sched_step_f32_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, noise, coef,
                        (long)n, prev, x0_out);
@@ -252,6 +261,7 @@ extern "C" int iir_sched_step_f32(const float* eps, const float* x, const float*
 }
 
 extern "C" int iir_axpby_f32(const float* x, const float* y, const float* coef, int64_t n, float* out, void* stream) {
+    (void)hipGetLastError();
     if (!x || !y || !coef || !out || n <= 0) return IIR_EINVAL;
     hipLaunchKernelGGL(axpby_f32_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, coef, (long)n, out);
     return iir_launch_status();

@@ -111,6 +111,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; importing it first makes our library bind to that same
+    # runtime instance (one HIP runtime per process), otherwise torch streams/pointers are foreign to us.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with instantir_amd/csrc/build.sh (hipcc --offload-arch=gfx950). "

@@ -27,6 +27,55 @@ def _chk2d(t, name):
         raise ValueError(f"{name}: expected a 2-D fp16 CUDA tensor with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
 
 
+class LaunchProfiler:
+    """Optional per-launch timing of the MFMA kernels with HIP events on the launch stream
+    (bench.py's roofline leg).  Records (kernel class, algorithmic FLOPs, start, stop)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for cls, flops, e0, e1 in self.records:
+            d = out.setdefault(cls, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return out
+
+
+PROFILER = None     # set to a LaunchProfiler to time gemm / conv / attention launches
+
+_TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64"}
+
+
+def auto_tile(M, N):
+    """Same rule as `dispatch()` in csrc/gemm_conv.hip (kept in sync so profiles can name the kernel)."""
+    blocks = lambda bm, bn: ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+    if blocks(128, 128) >= 384:
+        return 1
+    if blocks(128, 64) >= 256:
+        return 2
+    return 3
+
+
+class _Timed:
+    def __init__(self, cls, flops):
+        self.cls, self.flops = cls, flops
+
+    def __enter__(self):
+        if PROFILER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if PROFILER is not None:
+            self.e1.record()
+            PROFILER.records.append((self.cls, self.flops, self.e0, self.e1))
+
+
 _zero_pages = {}
 
 
@@ -61,8 +110,11 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     if res is not None:
         _chk2d(res, "res")
         d.res, d.ldr = res.data_ptr(), res.stride(0)
+    if tile == 0:
+        tile = auto_tile(M, N)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
-    L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
+    with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile], 2.0 * M * N * K):
+        L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out
 
 
@@ -90,10 +142,16 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     if res is not None:
         _chk2d(res, "res")
         d.res, d.ldr = res.data_ptr(), res.stride(0)
+    Hi, Wi = (2 * H, 2 * Wd) if upsample else (H, Wd)
+    pad = ksize // 2
+    Mo = R * ((Hi + 2 * pad - ksize) // stride + 1) * ((Wi + 2 * pad - ksize) // stride + 1)
+    if tile == 0:
+        tile = auto_tile(Mo, Cout)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     d.zero_page = zero_page(x.device).data_ptr()
     d.x_img_stride, d.y_img_rows, d.res_img_rows = x.stride(0), y_img_rows, res_img_rows
-    L.check(L.load().iir_conv2d_nhwc_f16(C.byref(d), _stream()), "iir_conv2d_nhwc_f16")
+    with _Timed("gemm_kernel<%s,conv>" % _TILE_NAMES[tile], 2.0 * Mo * Cout * ksize * ksize * Cin):
+        L.check(L.load().iir_conv2d_nhwc_f16(C.byref(d), _stream()), "iir_conv2d_nhwc_f16")
     return out
 
 
@@ -110,7 +168,8 @@ def attention(q, o, kv, batch, heads, Tq, scale=0.125):
         d.kv[i].K, d.kv[i].ldk, d.kv[i].k_batch_stride = k.data_ptr(), k.stride(0), k_rows * k.stride(0)
         d.kv[i].Vt, d.kv[i].ldvt, d.kv[i].vt_batch_stride = vt.data_ptr(), vt.stride(0), vbs
         d.kv[i].Tkv = tkv
-    L.check(L.load().iir_attention_d64_f16(C.byref(d), _stream()), "iir_attention_d64_f16")
+    with _Timed("attn_kernel", 4.0 * batch * heads * Tq * 64 * sum(k[4] for k in kv)):
+        L.check(L.load().iir_attention_d64_f16(C.byref(d), _stream()), "iir_attention_d64_f16")
     return o
 
 

@@ -1,0 +1,82 @@
+"""Multi-GPU side of the denoising path: one process per GPU, images sharded across ranks, no
+per-step collective.  The only exchange is the one-time broadcast of the frozen weights from rank 0
+over RCCL/xGMI -- done in large flat buckets so each collective is bandwidth-,
+not latency-bound on the point-to-point links."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env():
+    """(rank, world, local_rank, device).  backend "nccl" is RCCL on ROCm; gloo on CPU (tests)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device(f"cuda:{local}" if use_gpu else "cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+    return rank, world, local, device
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous split of the image list (infer.py:151-169 forms the list; ranks take slices)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_state_dict(sd: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 1 << 30) -> Dict[str, torch.Tensor]:
+    """In-place broadcast of every tensor of `sd` (same names/shapes on all ranks) in flat buckets."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return sd
+    names = sorted(sd)
+    bucket: List[str] = []
+    size = 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([sd[n].reshape(-1) for n in bucket])
+        dist.broadcast(flat, src)
+        off = 0
+        for n in bucket:
+            k = sd[n].numel()
+            sd[n].copy_(flat[off:off + k].view_as(sd[n]))
+            off += k
+        bucket, size = [], 0
+
+    cur_dtype = None
+    for n in names:
+        t = sd[n]
+        if cur_dtype is not None and t.dtype != cur_dtype:
+            flush()
+        cur_dtype = t.dtype
+        bucket.append(n)
+        size += t.numel() * t.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+    return sd
+
+
+def max_over_ranks(x: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
