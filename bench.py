@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="single stream (no encoder/previewer overlap)")
     args = ap.parse_args()
 
     from instantir_amd import lib, ops, parallel, weights as W
@@ -91,6 +92,7 @@ def main():
     pipe.aggregator.load_state_dict(sda)
     pipe.prepare_previewers(lora, lora_alpha=cfg.lora_rank // 8)
     pipe.use_graphs = not args.no_graph
+    pipe.overlap_streams = not args.no_overlap
     pipe._build()
     log(f"engines built ({time.time() - t0:.1f} s)")
     n_params = sum(v.numel() for v in sd.values()) + sum(v.numel() for v in sda.values())

@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int BK = 64;   // halfs per K tile = one 128-byte LDS row
+#define IIR_DEFAULT_STAGES 2
 
 struct Geo {   // per-launch constants shared by GEMM and CONV paths
     const f16* A; long lda;
@@ -41,14 +42,24 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     int tiles_m, tiles_n;
 };
 
-template <int BM, int BN, bool CONV>
+constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
+
+// wait until at most N of this wave's vector-memory ops (the LDS-DMA loads) are outstanding, then barrier.
+// One asm statement with a memory clobber: no LDS access may be scheduled across it.
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int ST, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
     constexpr int WM = BM / 2, WN = BN / 2;      // wave tile
     constexpr int MI = WM / 16, NI = WN / 16;    // 16x16 MFMA tiles per wave
     constexpr int A_INST = BM / 32, B_INST = BN / 32;   // glds instructions per wave per K tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* As = (f16*)smem;                       // [2][BM][64]
-    f16* Bs = As + 2 * BM * BK;                 // [2][BN][64]
+    f16* As = (f16*)smem;                       // [ST][BM][64]
+    f16* Bs = As + ST * BM * BK;                // [ST][BN][64]
+    constexpr int LOADS = A_INST + B_INST;      // LDS-DMA instructions per wave per stage
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -138,14 +149,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- main loop: ST-deep LDS ring, tiles kt+1 .. kt+ST-2 stay in flight across the barrier ---------
+    // (one barrier per K tile; the buffer refilled after the barrier is the one every wave finished
+    //  reading before it arrived there)
     const int nk = g.K / BK;
-    stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only (gfx9: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8])
-    __syncthreads();
-
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+        if (s < nk) stage(s, s);
+    int cur = 0, nxt = ST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const int ahead = nk - 1 - kt;                  // tiles issued after kt (capped at ST-2 below)
+        if (ST >= 4 && ahead >= 2) wait_vm_and_barrier<(ST >= 4 ? (ST - 2) * LOADS : 0)>();
+        else if (ST >= 3 && ahead >= 1) wait_vm_and_barrier<(ST >= 4 ? (ST - 3) * LOADS : (ST == 3 ? LOADS : 0))>();
+        else wait_vm_and_barrier<0>();
+        if (kt + ST - 1 < nk) stage(kt + ST - 1, nxt);
         const char* as = (const char*)(As + cur * BM * BK);
         const char* bs = (const char*)(Bs + cur * BN * BK);
 #pragma unroll
@@ -161,8 +178,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's glds for tile kt+1 have landed
-        __syncthreads();
+        cur = cur + 1 == ST ? 0 : cur + 1;
+        nxt = nxt + 1 == ST ? 0 : nxt + 1;
     }
 
     // ---- epilogue: lane holds row m = ..+frow, 4 consecutive columns n = ..+4*fq+{0..3} ---------
@@ -219,38 +236,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int ST>
 int launch(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = 2 * (BM + BN) * BK * sizeof(f16);
+    const size_t lds = ST * (BM + BN) * BK * sizeof(f16);
     const dim3 grid(g.tiles_m * g.tiles_n), block(256);
     if (conv) {
         static bool attr_c = false;
-        if (!attr_c) { hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, block, lds, stream, g);
+        if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, ST, true>), grid, block, lds, stream, g);
     } else {
         static bool attr_g = false;
-        if (!attr_g) { hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, lds, stream, g);
+        if (!attr_g) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, ST, false>), grid, block, lds, stream, g);
     }
     return iir_launch_status();
 }
 
 int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
-    // tile: 0 = auto.  Auto picks the largest tile that still yields >= ~1.5 waves of blocks on
-    // 256 CUs (2 blocks/CU resident); the paired epilogues need BN >= 64 (NI even).
+    // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64}; t + 10*stages selects the LDS ring depth.
     if (tile == 0) {
         auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
         if (blocks(128, 128) >= 384) tile = 1;
         else if (blocks(128, 64) >= 256) tile = 2;
         else tile = 3;
     }
+    if (tile < 10) tile += 10 * IIR_DEFAULT_STAGES;
     switch (tile) {
-        case 1: return launch<128, 128>(g, conv, stream);
-        case 2: return launch<128, 64>(g, conv, stream);
-        case 3: return launch<64, 64>(g, conv, stream);
+        case 21: return launch<128, 128, 2>(g, conv, stream);
+        case 31: return launch<128, 128, 3>(g, conv, stream);
+        case 41: return launch<128, 128, 4>(g, conv, stream);
+        case 22: return launch<128, 64, 2>(g, conv, stream);
+        case 32: return launch<128, 64, 3>(g, conv, stream);
+        case 42: return launch<128, 64, 4>(g, conv, stream);
+        case 23: return launch<64, 64, 2>(g, conv, stream);
+        case 33: return launch<64, 64, 3>(g, conv, stream);
+        case 43: return launch<64, 64, 4>(g, conv, stream);
         default: return IIR_EINVAL;
     }
 }

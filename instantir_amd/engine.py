@@ -500,13 +500,33 @@ class HipUNet(_Net):
         self.arena.reset()
         return self._forward(sample, t_dev, st, down_res, mid_res, res_scale)
 
+    def encode(self, sample, t_dev, st):
+        """First half (embeddings, conv_in, down blocks, mid block): independent of the Aggregator residuals,
+        so the caller may run it on a side stream while the previewer UNet / Aggregator run."""
+        self.arena.reset()
+        return self._encode(sample, t_dev, st)
+
+    def decode(self, enc, st, down_res=None, mid_res=None, res_scale=None):
+        """Second half (residual adds, up blocks, conv_out) on the state returned by `encode`."""
+        return self._decode(enc, st, down_res, mid_res, res_scale)
+
     def _forward(self, sample, t_dev, st, down_res, mid_res, res_scale):
+        return self._decode(self._encode(sample, t_dev, st), st, down_res, mid_res, res_scale)
+
+    def _encode(self, sample, t_dev, st):
         cfg, o, w, A = self.cfg, self.o, self.w, self.arena
         R, H, W = st["R"], st["H"], st["W"]
         temb_all, ada = self._embeddings(t_dev, st)
         x = A.alloc(R * H * W, cfg.block_out_channels[0])
         o.conv2d(sample.view(R, H, W, CPAD), w["conv_in.w"], x, bias=w["conv_in.b"])
         x, h, wd, skips = self._down_and_mid(x, R, H, W, temb_all, ada, st)
+        return x, h, wd, skips, temb_all, ada
+
+    def _decode(self, enc, st, down_res, mid_res, res_scale):
+        cfg, o, w, A = self.cfg, self.o, self.w, self.arena
+        R = st["R"]
+        x, h, wd, skips, temb_all, ada = enc
+        skips = list(skips)
         rev = list(reversed(cfg.block_out_channels))
         depth = list(reversed(cfg.transformer_depth))
         nb = len(rev)

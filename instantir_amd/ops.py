@@ -113,7 +113,7 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     if tile == 0:
         tile = auto_tile(M, N)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
-    with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile], 2.0 * M * N * K):
+    with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile % 10], 2.0 * M * N * K):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out
 
@@ -150,7 +150,7 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     d.zero_page = zero_page(x.device).data_ptr()
     d.x_img_stride, d.y_img_rows, d.res_img_rows = x.stride(0), y_img_rows, res_img_rows
-    with _Timed("gemm_kernel<%s,conv>" % _TILE_NAMES[tile], 2.0 * Mo * Cout * ksize * ksize * Cin):
+    with _Timed("gemm_kernel<%s,conv>" % _TILE_NAMES[tile % 10], 2.0 * Mo * Cout * ksize * ksize * Cin):
         L.check(L.load().iir_conv2d_nhwc_f16(C.byref(d), _stream()), "iir_conv2d_nhwc_f16")
     return out
 
@@ -177,11 +177,13 @@ _gn_ws = {}
 
 
 def _gn_workspace(device, R, groups):
+    """fp32 partial-sum scratch, one per (device, stream): launches on different streams may overlap."""
     need = L.load().iir_groupnorm_workspace_bytes(R, groups)
-    ws = _gn_ws.get(device)
+    key = (device, _stream())
+    ws = _gn_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=device)
-        _gn_ws[device] = ws
+        _gn_ws[key] = ws
     return ws
 
 

@@ -70,6 +70,7 @@ class InstantIRPipeline:
         self._unet = self._unet_prev = self._agg = None
         self._graphs = {}
         self.use_graphs = True
+        self.overlap_streams = True
         self._guidance_scale = 7.0
 
     # ---- reference surface ----------------------------------------------------------------------
@@ -352,11 +353,36 @@ class _DenoiseLoop:
         self.sched_coef = self.sc_dev[R + 4:R + 12]
         self.res_scale = self.sc_dev[R + 12:]
         self.graphs = {}
+        self.side = None
 
     def _launch(self, mode, use_noise, want_x0, want_preview):
         p, B, rep = self.p, self.B, self.rep
         ops.pack_latent(self.x_in, self.lat16, rep=rep)                      # cat([latents]*2), :1503
         down = mid = None
+        if mode != "unet" and p.overlap_streams:
+            # The main UNet's encoder half does not depend on the previewer / Aggregator: run it on a side
+            # stream so its (CU-underfilling) launches overlap theirs; join before the residual adds.
+            main = torch.cuda.current_stream()
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=self.x_in.device)
+            fork, join = torch.cuda.Event(), torch.cuda.Event()
+            fork.record(main)
+            self.side.wait_event(fork)
+            with torch.cuda.stream(self.side):
+                enc = p._unet.encode(self.lat16, self.t_dev, self.st)
+                join.record(self.side)
+            if mode == "preview":
+                eps1 = p._unet_prev.forward(self.lat16, self.t_dev, self.st_prev)
+                ops.lcm_step(eps1, B, rep, self.lcm_coef, self.x_in, self.prev16, self.preview_f32 if want_preview else None)
+                cond = self.prev16
+            else:
+                cond = self.ref16 if self.ref16 is not None else self.lq16
+            down, mid = p._agg.forward(self.lq16, cond, self.t_dev, self.st_agg)
+            main.wait_event(join)
+            eps = p._unet.decode(enc, self.st, down, mid, self.res_scale)
+            ops.sched_step(eps, B, self.sched_coef, self.x_in, self.x_out, noise=self.noise if use_noise else None,
+                           cfg=rep == 2, x0_out=self.x0 if want_x0 else None)
+            return
         if mode != "unet":
             if mode == "preview":
                 eps1 = p._unet_prev.forward(self.lat16, self.t_dev, self.st_prev)          # :1545-1554

@@ -6,6 +6,7 @@ from instantir_amd import ops
 from instantir_amd.packing import conv_weight_nhwc
 
 dev = torch.device("cuda:0")
+TILES = (21, 31, 41, 22, 32, 42, 23, 33, 43)
 
 def timeit(fn, iters=20, warm=3):
     for _ in range(warm): fn()
@@ -24,9 +25,9 @@ def gemm_bench():
         a = torch.randn(M, K, device=dev).half(); w = (torch.randn(N, K, device=dev) * K ** -0.5).half()
         out = torch.empty(M, N, device=dev, dtype=torch.half)
         row = f"gemm M={M:6d} N={N:6d} K={K:5d}:"
-        for tile in (1, 2, 3):
+        for tile in TILES:
             t = timeit(lambda: ops.gemm(a, w, out, tile=tile))
-            row += f"  t{tile} {2*M*N*K/t/1e12:7.1f} TF ({t*1e6:7.1f} us)"
+            row += f"  t{tile} {2*M*N*K/t/1e12:6.0f}"
         t = timeit(lambda: torch.matmul(a, w.T, out=out))
         row += f"  | hipblaslt {2*M*N*K/t/1e12:7.1f} TF"
         print(row, flush=True)
@@ -37,9 +38,9 @@ def conv_bench():
         out = torch.empty(R * H * H, Cout, device=dev, dtype=torch.half)
         row = f"conv R={R} H={H:4d} Cin={Cin:5d} Cout={Cout:5d}:"
         fl = 2 * R * H * H * Cout * 9 * Cin
-        for tile in (1, 2, 3):
+        for tile in TILES:
             t = timeit(lambda: ops.conv2d(x, w, out, tile=tile))
-            row += f"  t{tile} {fl/t/1e12:7.1f} TF ({t*1e6:7.1f} us)"
+            row += f"  t{tile} {fl/t/1e12:6.0f}"
         print(row, flush=True)
 
 def attn_bench():
