@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--prefetch", action="store_true", help="enable the side-stream weight prefetcher (experimental)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no encoder/previewer overlap)")
     args = ap.parse_args()
 
@@ -94,6 +95,8 @@ def main():
     pipe.use_graphs = not args.no_graph
     pipe.overlap_streams = not args.no_overlap
     pipe._build()
+    for net in (pipe._unet, pipe._unet_prev, pipe._agg):
+        net.prefetch = args.prefetch
     log(f"engines built ({time.time() - t0:.1f} s)")
     n_params = sum(v.numel() for v in sd.values()) + sum(v.numel() for v in sda.values())
     cpu_sd = None

@@ -145,6 +145,11 @@ int iir_sched_step_f32(const float* eps, const float* x, const float* noise, con
                        float* x0_out, void* stream);
 int iir_axpby_f32(const float* x, const float* y, const float* coef, int64_t n, float* out, void* stream);
 
+/* Weight prefetch: touches every 128-byte line of [p, p+bytes) with `blocks` workgroups so the range
+ * sits in the 256 MiB Infinity Cache when the GEMM/conv that streams it starts (the reference has no
+ * counterpart: PyTorch streams each layer's weights cold from HBM). */
+int iir_prefetch(const void* p, int64_t bytes, int32_t blocks, void* stream);
+
 int iir_transpose_f16(const void* in, int64_t ldi, int32_t rows, int32_t cols, void* out, int64_t ldo, int32_t rows_pad,
                       void* stream);
 int iir_abi_version(void);

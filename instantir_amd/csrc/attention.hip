@@ -25,6 +25,8 @@ struct AGeo {
     const f16* Q; long ldq, qbs;
     f16* O; long ldo, obs;
     int Tq, nseg;
+    int qtiles, npairs;   // query tiles per (batch, head); number of (batch, head) pairs; heads below
+    int heads;
     float c;   // softmax scale * log2(e)
     Seg seg[2];
 };
@@ -39,8 +41,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qi = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware placement: workgroups b, b+8, ... share an XCD (one L2).  Give each XCD a contiguous run of
+    // the (batch, head)-major tile order so a pair's K / V^T is pulled over the fabric by 1-2 L2s, not all 8.
+    // (bijective chunked remap: XCD x gets the contiguous run [start_x, start_x + len_x) of the pair-major order)
+    int lin;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = blockIdx.x & 7;
+        lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+    }
+    const int pair = lin / g.qtiles;
+    const int h = pair % g.heads, b = pair / g.heads;
+    const int q0 = (lin % g.qtiles) * 128 + wave * 32;
 
     // Q fragments: B operand of S^T = K.Q^T -- lane (q, hh) holds d = 16*ks + 8*hh + [0,8)
     f16x8 qf[4];
@@ -101,15 +112,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
             const char* kt = Ks + buf * KT * 128;
             const char* vt = Vs + buf * KT * 128;
 
-            // ---- S^T = K . Q^T  (2 blocks of 32 keys)
+            // ---- S^T = K . Q^T  (2 blocks of 32 keys); first k-step accumulates onto the inline constant 0
             f32x16 sacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
+                const char* krow = kt + (kb * 32 + qi) * 128;
+                const int sw = qi & 7;
+                f16x8 kf = *(const f16x8*)(krow + ((hh ^ sw) * 16));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const f16x8 kf = *(const f16x8*)(kt + (kb * 32 + qi) * 128 + (((2 * ks + hh) ^ (qi & 7)) * 16));
+                for (int ks = 1; ks < 4; ++ks) {
+                    kf = *(const f16x8*)(krow + (((2 * ks + hh) ^ sw) * 16));
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
                 }
             }
@@ -123,7 +136,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
                         if (key >= s.Tkv) sacc[kb][r] = -INFINITY;
                     }
             }
-            // ---- online softmax (base 2)
+            // ---- online softmax (base 2).  The O / l rescale runs only when some row's running max grew
+            //      (alpha == 1 exactly otherwise), which after the first tiles is rare.
             float mx = sacc[0][0];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -131,22 +145,25 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx * g.c);
-            const float alpha = exp2f(m - m_new);
+            if (__any(m_new > m)) {
+                const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+                l *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                m = m_new;
+            }
             float lsum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(fmaf(sacc[kb][r], g.c, -m_new));
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], g.c, -m));
                     sacc[kb][r] = p;
                     lsum += p;
                 }
-            l = l * alpha + lsum;
-            m = m_new;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            l += lsum;
 
             // ---- O^T += V^T . P^T : k-step (kb, sp) covers keys 32kb+16sp+[0,16) in the permuted order
             //      element j of lane half hh <-> key 16*sp' + 8*(j>>2) + 4*hh + (j&3)
@@ -165,9 +182,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
                         const char* row = vt + d * 128;
                         const f16x4 lo = *(const f16x4*)(row + (((key_lo >> 3) ^ sw) * 16) + (key_lo & 7) * 2);
                         const f16x4 hi = *(const f16x4*)(row + ((((key_lo + 8) >> 3) ^ sw) * 16) + (key_lo & 7) * 2);
-                        f16x8 vf;
-                        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                        const f16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[db], 0, 0, 0);
                     }
                 }
@@ -215,7 +230,10 @@ extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
         if (!s->K || !s->Vt || s->Tkv <= 0 || s->ldk % 8 || s->ldvt % 8 || s->vt_batch_stride % 8) return IIR_EINVAL;
         g.seg[i] = Seg{(const f16*)s->K, s->ldk, s->k_batch_stride, (const f16*)s->Vt, s->ldvt, s->vt_batch_stride, s->Tkv};
     }
-    const dim3 grid((a->Tq + 127) / 128, a->heads, a->batch);
+    g.qtiles = (a->Tq + 127) / 128;
+    g.npairs = a->heads * a->batch;
+    g.heads = a->heads;
+    const dim3 grid(g.npairs * g.qtiles);
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     return iir_launch_status();
 }

@@ -6,10 +6,14 @@ OUT=../libinstantir_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -w"
 mkdir -p build
 pids=()
-for f in gemm_conv attention norm; do
+for f in gemm_conv norm; do
   hipcc $FLAGS -c $f.hip -o build/$f.o &
   pids+=($!)
 done
+# attention: keep MFMA accumulators in VGPRs (softmax reads/rescales them every tile; AGPR form costs
+# a v_accvgpr_read/write pair per touched element)
+hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 -c attention.hip -o build/attention.o &
+pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c pointwise.hip -o build/pointwise.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done

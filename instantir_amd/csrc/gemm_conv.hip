@@ -18,11 +18,18 @@
 // columns of one row -> 8-byte packed stores and 8-byte bias/residual loads in the epilogue.
 #include "common.h"
 #include "../../include/instantir_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 64;   // halfs per K tile = one 128-byte LDS row
 #define IIR_DEFAULT_STAGES 2
+#ifndef IIR_T1_MIN
+#define IIR_T1_MIN 384
+#endif
+#ifndef IIR_T2_MIN
+#define IIR_T2_MIN 256
+#endif
 
 struct Geo {   // per-launch constants shared by GEMM and CONV paths
     const f16* A; long lda;
@@ -40,6 +47,7 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     long x_img_stride;        // elements between input images
     int y_img_rows, res_img_rows;   // rows between images in C / res (conv mode); 0 = dense
     int tiles_m, tiles_n;
+    int xm, rm, rn;           // XCD partition: xm x (8/xm) rectangles of rm x rn tiles
 };
 
 constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
@@ -66,14 +74,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile order (blocks b, b+8, ... share an XCD/L2): give each XCD a contiguous run of
-    // tiles that walks M fastest, so co-resident blocks of one XCD share the same weight panel.
-    int bid = blockIdx.x;
+    // XCD-aware tile order.  Workgroups b, b+8, b+16, ... share an XCD (= one private L2).  The tile grid is
+    // cut into 8 rectangles (xm x 8/xm), one per XCD, chosen on the host to minimise the operand bytes each
+    // L2 has to pull over the fabric; inside a rectangle tiles walk M fastest so co-resident workgroups
+    // share a weight panel.  Placement only affects speed, never results.
+    int tm, tn;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+        const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+        const int rx = xcd % g.xm, ry = xcd / g.xm;
+        tm = rx * g.rm + local % g.rm;
+        tn = ry * g.rn + local / g.rm;
+        if (tm >= g.tiles_m || tn >= g.tiles_n) return;     // padding workgroup of a ragged rectangle
     }
-    const int tm = bid % g.tiles_m, tn = bid / g.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-lane staging addresses -------------------------------------------------------------
@@ -242,7 +254,17 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     const size_t lds = ST * (BM + BN) * BK * sizeof(f16);
-    const dim3 grid(g.tiles_m * g.tiles_n), block(256);
+    // pick the XCD partition with the least per-L2 operand rows: (tiles_m/xm)*BM + (tiles_n/xn)*BN
+    long best = -1;
+    static const int force_xm = getenv("IIR_XM") ? atoi(getenv("IIR_XM")) : 0;   // tuning knob: 1,2,4,8 forces the split
+    for (int xm = 1; xm <= 8; xm *= 2) {
+        if (force_xm && xm != force_xm) continue;
+        const int xn = 8 / xm;
+        const int rm = (g.tiles_m + xm - 1) / xm, rn = (g.tiles_n + xn - 1) / xn;
+        const long cost = (long)rm * BM + (long)rn * BN + ((long)rm * rn * 8 - (long)g.tiles_m * g.tiles_n) * 8;
+        if (best < 0 || cost < best) { best = cost; g.xm = xm; g.rm = rm; g.rn = rn; }
+    }
+    const dim3 grid(8 * g.rm * g.rn), block(256);
     if (conv) {
         static bool attr_c = false;
         if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
@@ -259,8 +281,8 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64}; t + 10*stages selects the LDS ring depth.
     if (tile == 0) {
         auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
-        if (blocks(128, 128) >= 384) tile = 1;
-        else if (blocks(128, 64) >= 256) tile = 2;
+        if (blocks(128, 128) >= IIR_T1_MIN) tile = 1;
+        else if (blocks(128, 64) >= IIR_T2_MIN) tile = 2;
         else tile = 3;
     }
     if (tile < 10) tile += 10 * IIR_DEFAULT_STAGES;

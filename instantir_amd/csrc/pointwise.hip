@@ -266,3 +266,22 @@ extern "C" int iir_axpby_f32(const float* x, const float* y, const float* coef, 
     hipLaunchKernelGGL(axpby_f32_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, coef, (long)n, out);
     return iir_launch_status();
 }
+
+namespace {
+// Touch one dword per 128-byte line of [p, p+bytes): pulls the range from HBM into the memory-side
+// Infinity Cache (and the issuing XCD's L2) ahead of the GEMM that will stream it.
+__global__ void prefetch_kernel(const char* p, long nlines) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    for (; i < nlines; i += stride) acc ^= *(const volatile unsigned*)(p + i * 128);
+    asm volatile("" ::"v"(acc));
+}
+}  // namespace
+
+extern "C" int iir_prefetch(const void* p, int64_t bytes, int32_t blocks, void* stream) {
+    (void)hipGetLastError();
+    if (!p || bytes <= 0 || blocks <= 0) return IIR_EINVAL;
+    hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)p, (long)(bytes / 128));
+    return iir_launch_status();
+}

@@ -100,6 +100,21 @@ def _merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], scal
     return out
 
 
+class _RecDict(dict):
+    """Weight dict that reports every lookup (used once, in the dry run, to learn the order of use)."""
+
+    def __init__(self, base, note):
+        super().__init__(base)
+        self._note = note
+
+    def __getitem__(self, k):
+        self._note(k)
+        return dict.__getitem__(self, k)
+
+
+PREFETCH_BLOCKS = 48      # workgroups of the weight prefetcher: a trickle beside the GEMMs, not a competitor
+
+
 class _Net:
     """Shared machinery: packed weights, arena, resnet / transformer executors."""
 
@@ -112,6 +127,15 @@ class _Net:
         self.w: Dict[str, torch.Tensor] = {}
         self._temb_slices: Dict[str, slice] = {}
         self._ada_slices: Dict[str, slice] = {}
+        # weight streaming state: `units` = (ptr, bytes) of the weights first used by each resnet /
+        # transformer block / SFT head, in execution order inside ONE contiguous weight arena
+        self.units: List[tuple] = []
+        self._use_log: Optional[list] = None
+        self._unit_idx = 0
+        self.prefetch = False     # side-stream weight prefetch: measured slower under hipGraph replay
+        self._pf_stream = None
+        self._pf_forked = False
+        self._gnws = None
         self._pack_encoder(sd)
 
     # ---- weight packing ---------------------------------------------------------------------
@@ -213,16 +237,91 @@ class _Net:
         """Dry-run `fn` (launches skipped) to find the arena high-water mark, then allocate it."""
         self.arena.buf, self.arena.off, self.arena.high = None, 0, 0
         self.o = _NullOps()
+        plain = self.w
+        first = not self.units
+        self._gnws = ops.gn_workspace(self.device, 64, self.cfg.norm_groups)
+        if first:
+            self._use_log = []
+            self.w = _RecDict(plain, lambda k: self._use_log.append(k))
         try:
             fn()
         finally:
             self.o = ops
+            self.w = plain
+        if first:
+            self._consolidate_weights()
         self.arena.reserve(self.arena.high + 1024)
         self.arena.reset()
+
+    def _consolidate_weights(self):
+        """Re-home every packed weight into one contiguous fp16 arena ordered by first use in the forward
+        (so the weights of a block are one address range the prefetcher can pull ahead of the GEMMs)."""
+        order, seen, marks = [], set(), []
+        for k in self._use_log:
+            if isinstance(k, tuple):            # ("unit", name) marker
+                marks.append(len(order))
+            elif k not in seen:
+                seen.add(k)
+                order.append(k)
+        order += [k for k in self.w if k not in seen]
+        al = lambda n: (n + 127) // 128 * 128
+        offs, tot = [], 0
+        for k in order:
+            offs.append(tot)
+            tot += al(self.w[k].numel())
+        arena = torch.empty(tot, dtype=F16, device=self.device)
+        for k, off in zip(order, offs):
+            t = self.w[k]
+            v = arena[off:off + t.numel()].view(t.shape)
+            v.copy_(t)
+            self.w[k] = v
+        self._warena = arena
+        n_used = len(seen)
+        bounds = marks + [n_used]
+        self.units = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            lo = offs[a] if a < len(offs) else tot
+            hi = offs[b] if b < len(offs) else tot
+            self.units.append((arena.data_ptr() + 2 * lo, 2 * (hi - lo)))
+        self._use_log = None
+
+    def _unit(self, name):
+        """Called at the start of every resnet / transformer block / SFT head."""
+        if self._use_log is not None:
+            self._use_log.append(("unit", name))
+            return
+        if self.o is not ops:
+            return
+        k = self._unit_idx
+        self._unit_idx += 1
+        if not self.prefetch or k + 1 >= len(self.units) or self.units[k + 1][1] < (1 << 20):
+            return
+        cur = torch.cuda.current_stream()
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._pf_stream.wait_event(ev)
+        with torch.cuda.stream(self._pf_stream):
+            ops.prefetch(self.units[k + 1][0], self.units[k + 1][1], PREFETCH_BLOCKS)
+        self._pf_forked = True
+
+    def _begin(self):
+        self.arena.reset()
+        self._unit_idx = 0
+
+    def _join_prefetch(self):
+        """The prefetch stream forked from the compute stream must rejoin it (hipGraph capture rule)."""
+        if self._pf_forked:
+            ev = torch.cuda.Event()
+            ev.record(self._pf_stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._pf_forked = False
 
     # ---- blocks -----------------------------------------------------------------------------
     def _resnet(self, path, x, R, H, W, temb_all, out=None, eps=1e-5):
         """x (R*H*W, Cin) view -> (R*H*W, Cout).  module/min_sdxl.py:261-283."""
+        self._unit(path)
         o, w, A = self.o, self.w, self.arena
         HW = H * W
         cin = x.shape[1]
@@ -231,12 +330,12 @@ class _Net:
             out = A.alloc(R * HW, cout)
         m = A.mark()
         h = A.alloc(R * HW, cin)
-        o.groupnorm(x, h, R, HW, w[path + ".norm1.g"], w[path + ".norm1.b"], eps, True, self.cfg.norm_groups)
+        o.groupnorm(x, h, R, HW, w[path + ".norm1.g"], w[path + ".norm1.b"], eps, True, self.cfg.norm_groups, self._gnws)
         h2 = A.alloc(R * HW, cout)
         o.conv2d(h.view(R, H, W, cin), w[path + ".conv1.w"], h2, bias=w[path + ".conv1.b"],
                  rowbias=temb_all[:, self._temb_slices[path]], rows_per_rb=HW)
         h3 = A.alloc(R * HW, cout)
-        o.groupnorm(h2, h3, R, HW, w[path + ".norm2.g"], w[path + ".norm2.b"], eps, True, self.cfg.norm_groups)
+        o.groupnorm(h2, h3, R, HW, w[path + ".norm2.g"], w[path + ".norm2.b"], eps, True, self.cfg.norm_groups, self._gnws)
         if (path + ".conv_shortcut.w") in w:
             sc = A.alloc(R * HW, cout)
             o.gemm(x, w[path + ".conv_shortcut.w"], sc, bias=w[path + ".conv_shortcut.b"])
@@ -248,6 +347,7 @@ class _Net:
 
     def _tblock(self, p, h, R, T, heads, st, ada):
         """One BasicTransformerBlock in place on h (R*T, C).  module/min_sdxl.py:541-562."""
+        self._unit(p)
         o, w, A = self.o, self.w, self.arena
         C = h.shape[1]
         M = R * T
@@ -297,7 +397,7 @@ class _Net:
             out = A.alloc(R * T, C)
         m = A.mark()
         g = A.alloc(R * T, C)
-        o.groupnorm(x, g, R, T, w[path + ".norm.g"], w[path + ".norm.b"], 1e-6, False, self.cfg.norm_groups)
+        o.groupnorm(x, g, R, T, w[path + ".norm.g"], w[path + ".norm.b"], 1e-6, False, self.cfg.norm_groups, self._gnws)
         h = A.alloc(R * T, C)
         o.gemm(g, w[path + ".proj_in.w"], h, bias=w[path + ".proj_in.b"])
         for k in range(depth):
@@ -497,18 +597,24 @@ class HipUNet(_Net):
         down_res: list of (R*h*w, C) tensors added to the skips; mid_res likewise; res_scale: fp32 device (R,)
         per-row scale of the residuals (cond_scale, pipelines/sdxl_instantir.py:1602-1603).
         Returns eps as an (R*H*W, 4) fp16 NHWC view into the arena (valid until the next forward)."""
-        self.arena.reset()
-        return self._forward(sample, t_dev, st, down_res, mid_res, res_scale)
+        self._begin()
+        out = self._forward(sample, t_dev, st, down_res, mid_res, res_scale)
+        self._join_prefetch()
+        return out
 
     def encode(self, sample, t_dev, st):
         """First half (embeddings, conv_in, down blocks, mid block): independent of the Aggregator residuals,
         so the caller may run it on a side stream while the previewer UNet / Aggregator run."""
-        self.arena.reset()
-        return self._encode(sample, t_dev, st)
+        self._begin()
+        enc = self._encode(sample, t_dev, st)
+        self._join_prefetch()
+        return enc
 
     def decode(self, enc, st, down_res=None, mid_res=None, res_scale=None):
         """Second half (residual adds, up blocks, conv_out) on the state returned by `encode`."""
-        return self._decode(enc, st, down_res, mid_res, res_scale)
+        out = self._decode(enc, st, down_res, mid_res, res_scale)
+        self._join_prefetch()
+        return out
 
     def _forward(self, sample, t_dev, st, down_res, mid_res, res_scale):
         return self._decode(self._encode(sample, t_dev, st), st, down_res, mid_res, res_scale)
@@ -554,7 +660,7 @@ class HipUNet(_Net):
                 x, h, wd = y, 2 * h, 2 * wd
         c0 = cfg.block_out_channels[0]
         g = A.alloc(R * h * wd, c0)
-        o.groupnorm(x, g, R, h * wd, w["conv_norm_out.g"], w["conv_norm_out.b"], 1e-5, True, cfg.norm_groups)
+        o.groupnorm(x, g, R, h * wd, w["conv_norm_out.g"], w["conv_norm_out.b"], 1e-5, True, cfg.norm_groups, self._gnws)
         eps = A.alloc(R * h * wd, cfg.out_channels)
         o.conv2d(g.view(R, h, wd, c0), w["conv_out.w"], eps, bias=w["conv_out.b"])
         return eps
@@ -604,12 +710,15 @@ class HipAggregator(_Net):
     def forward(self, lq, preview, t_dev, st):
         """lq, preview: (R*H*W, 64) fp16 NHWC latents.  Returns (list of 9 residuals, mid residual),
         each (R*h*w, C) fp16 NHWC, un-scaled (conditioning_scale = 1, module/aggregator.py:963-964)."""
-        self.arena.reset()
-        return self._forward(lq, preview, t_dev, st)
+        self._begin()
+        out = self._forward(lq, preview, t_dev, st)
+        self._join_prefetch()
+        return out
 
     def _sft(self, p, s, R, h2, wd, out):
         """SFT + zero 1x1 on a (R, 2h, w, C) map: cond = top half, h = bottom half.
         module/aggregator.py:940-948, :76-86."""
+        self._unit(p)
         o, w, A, cfg = self.o, self.w, self.arena, self.cfg
         C = s.shape[1]
         h = h2 // 2

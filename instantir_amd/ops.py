@@ -50,12 +50,17 @@ PROFILER = None     # set to a LaunchProfiler to time gemm / conv / attention la
 _TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64"}
 
 
+import os as _os
+T1_MIN = int(_os.environ.get("IIR_T1_MIN", 384))
+T2_MIN = int(_os.environ.get("IIR_T2_MIN", 256))
+
+
 def auto_tile(M, N):
     """Same rule as `dispatch()` in csrc/gemm_conv.hip (kept in sync so profiles can name the kernel)."""
     blocks = lambda bm, bn: ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-    if blocks(128, 128) >= 384:
+    if blocks(128, 128) >= T1_MIN:
         return 1
-    if blocks(128, 64) >= 256:
+    if blocks(128, 64) >= T2_MIN:
         return 2
     return 3
 
@@ -187,11 +192,17 @@ def _gn_workspace(device, R, groups):
     return ws
 
 
-def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32):
-    """x, out: 2-D views (R*HW, C)."""
+def gn_workspace(device, R, groups=32):
+    """Caller-owned fp32 scratch for `groupnorm` (one per concurrently running network)."""
+    return torch.empty(L.load().iir_groupnorm_workspace_bytes(R, groups) // 4, dtype=torch.float32, device=device)
+
+
+def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32, ws=None):
+    """x, out: 2-D views (R*HW, C).  `ws`: scratch from gn_workspace() (a shared per-stream one if omitted)."""
     _chk2d(x, "x"); _chk2d(out, "out")
     Cc = x.shape[1]
-    ws = _gn_workspace(x.device, R, groups)
+    if ws is None:
+        ws = _gn_workspace(x.device, R, groups)
     L.check(L.load().iir_groupnorm_nhwc_f16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, HW, Cc, groups,
                                             gamma.data_ptr(), beta.data_ptr(), eps, int(silu), ws.data_ptr(),
                                             ws.numel() * 4, _stream()), "iir_groupnorm_nhwc_f16")
@@ -284,3 +295,8 @@ def axpby_f32(x, y, coef, out):
     L.check(L.load().iir_axpby_f32(x.data_ptr(), y.data_ptr(), coef.data_ptr(), x.numel(), out.data_ptr(), _stream()),
             "iir_axpby_f32")
     return out
+
+
+def prefetch(ptr, nbytes, blocks=32):
+    """Pull [ptr, ptr+nbytes) towards the Infinity Cache on the current stream."""
+    L.check(L.load().iir_prefetch(ptr, nbytes, blocks, _stream()), "iir_prefetch")

@@ -369,7 +369,11 @@ class _DenoiseLoop:
             fork.record(main)
             self.side.wait_event(fork)
             with torch.cuda.stream(self.side):
+                # no weight prefetch here: the encoder is the hidden branch, and forking a third stream off a
+                # side stream inside a capture crashed hipStreamEndCapture on ROCm 7.2 for some graph shapes
+                pf, p._unet.prefetch = p._unet.prefetch, False
                 enc = p._unet.encode(self.lat16, self.t_dev, self.st)
+                p._unet.prefetch = pf
                 join.record(self.side)
             if mode == "preview":
                 eps1 = p._unet_prev.forward(self.lat16, self.t_dev, self.st_prev)
