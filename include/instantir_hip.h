@@ -72,6 +72,8 @@ typedef struct iir_conv_desc {
     int64_t x_img_stride;          /* elements between input images; 0 = H*Wd*ldx (dense)          */
     int32_t y_img_rows;            /* rows between images in Y; 0 = Ho*Wo (dense)                  */
     int32_t res_img_rows;          /* rows between images in res; 0 = Ho*Wo                        */
+    int32_t pad_mode;              /* 0: symmetric ksize/2; 1: pad 0 top/left, 1 bottom/right (VAE  */
+                                   /*    Downsample2D(padding=0) + F.pad(0,1,0,1), vae.py:110)      */
 } iir_conv_desc;
 
 /* Replaces nn.Conv2d call sites: ResnetBlock2D module/min_sdxl.py:256-259,274 (+ the temb add :267 as
@@ -111,6 +113,11 @@ int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups);
 int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t rows, int32_t C, const void* gamma,
                       const void* beta, float eps, const void* shift, const void* scale, int64_t ldmod,
                       int32_t rows_per_mod, int32_t transposed, int32_t tr_rows, int64_t tr_bstride, void* stream);
+
+/* In-place row softmax (fp32 math) of an fp16 matrix, cols <= 16384: the score matrix of the VAE mid-block
+ * attention (1 head of dim 512, T = (H/8)*(W/8) tokens; torch.softmax inside F.scaled_dot_product_attention,
+ * module/ip_adapter/attention_processor.py:394 as used by module/unet/unet_2d_ZeroSFT_blocks.py:776-790). */
+int iir_softmax_rows_f16(void* X, int64_t ld, int32_t rows, int32_t cols, void* stream);
 
 /* Timesteps: module/min_sdxl.py:205-224.  out[r][col_off + v*dim + ...] = [cos | sin](vals[r][v] * w_k). */
 int iir_sinusoid_f16(const float* vals, int32_t n_vals, int32_t rows, int32_t dim, void* out, int64_t ldo,

@@ -329,11 +329,12 @@ extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
     if (c->epi != IIR_EPI_PLAIN && (c->Cout % 32)) return IIR_EINVAL;
     if (c->epi == IIR_EPI_SFT && !c->res) return IIR_EINVAL;
     if (c->rowbias && c->rows_per_rb <= 0) return IIR_EINVAL;
-    const int pad = c->ksize / 2;
+    const int pad = c->pad_mode == 1 ? 0 : c->ksize / 2;   // mode 1: taps reach 1 pixel past the bottom/right edge only
+    const int pad_hi = c->pad_mode == 1 ? 1 : pad;
     const int Hin = c->upsample ? 2 * c->H : c->H, Win = c->upsample ? 2 * c->Wd : c->Wd;
     Geo g{};
-    g.Ho = (Hin + 2 * pad - c->ksize) / c->stride + 1;
-    g.Wo = (Win + 2 * pad - c->ksize) / c->stride + 1;
+    g.Ho = (Hin + pad + pad_hi - c->ksize) / c->stride + 1;
+    g.Wo = (Win + pad + pad_hi - c->ksize) / c->stride + 1;
     g.A = (const f16*)c->X; g.lda = c->ldx; g.W = (const f16*)c->Wt; g.C = (f16*)c->Y; g.ldc = c->ldy;
     g.M = c->R * g.Ho * g.Wo; g.N = c->Cout; g.K = c->ksize * c->ksize * c->Cin;
     g.bias = (const f16*)c->bias; g.rowbias = (const f16*)c->rowbias; g.ldrb = c->ldrb; g.rows_per_rb = c->rows_per_rb;

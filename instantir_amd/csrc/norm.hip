@@ -53,51 +53,59 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* X, long ldx, i
     }
 }
 
-// ---- GroupNorm pass 2: finalize statistics (from the partials) + normalize + affine (+SiLU) ------
+// ---- GroupNorm pass 2: reduce the slab partials to mean / rstd per (image, group) ------------------
+__global__ void gn_finalize_kernel(const float* part, int nslab, int G, float n_per_group, float eps, float* stat /*[R][G][2]*/) {
+    const int r = blockIdx.x, gi = threadIdx.x;
+    if (gi >= G) return;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < nslab; ++k) {
+        const float* o = part + (((long)r * nslab + k) * G + gi) * 2;
+        s += o[0]; q += o[1];
+    }
+    const float mean = s / n_per_group;
+    const float var = fmaxf(q / n_per_group - mean * mean, 0.f);
+    stat[((long)r * G + gi) * 2] = mean;
+    stat[((long)r * G + gi) * 2 + 1] = rsqrtf(var + eps);
+}
+
+// ---- GroupNorm pass 3: normalize + affine (+SiLU).  A thread owns fixed 8-channel chunks, so its 16
+// scale/shift coefficients live in registers and the pixel loop is load - 8 fma - store.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, long ldx, f16* Y, long ldy, int HW, int C, int G,
-                                                       int pix_per_blk, const float* part, int nslab, const f16* gamma,
-                                                       const f16* beta, float eps, int silu) {
-    __shared__ float sa[GN_MAXC], sb[GN_MAXC];
-    __shared__ float gmean[64], grstd[64];
+                                                       int pix_per_blk, const float* stat, const f16* gamma,
+                                                       const f16* beta, int silu) {
     const int r = blockIdx.y;
     const int cpg = C / G;
-    if (threadIdx.x < G) {
-        float s = 0.f, q = 0.f;
-        for (int k = 0; k < nslab; ++k) {
-            const float* o = part + (((long)r * nslab + k) * G + threadIdx.x) * 2;
-            s += o[0]; q += o[1];
-        }
-        const float n = (float)HW * (float)cpg;
-        const float mean = s / n;
-        const float var = fmaxf(q / n - mean * mean, 0.f);
-        gmean[threadIdx.x] = mean;
-        grstd[threadIdx.x] = rsqrtf(var + eps);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const int gi = c / cpg;
-        const float a = grstd[gi] * (float)gamma[c];
-        sa[c] = a;
-        sb[c] = (float)beta[c] - gmean[gi] * a;
-    }
-    __syncthreads();
     const int nchunk = C >> 3;
+    const int lanes_c = nchunk < 256 ? nchunk : 256;
+    const int prows = 256 / lanes_c;
+    const int tc = threadIdx.x % lanes_c, tp = threadIdx.x / lanes_c;
+    if (tp >= prows) return;
     const int p0 = blockIdx.x * pix_per_blk;
     const int p1 = min(HW, p0 + pix_per_blk);
-    const long total = (long)(p1 - p0) * nchunk;
     const f16* xb = X + (long)r * HW * ldx;
     f16* yb = Y + (long)r * HW * ldy;
-    for (long i = threadIdx.x; i < total; i += 256) {
-        const int p = p0 + (int)(i / nchunk), ch = (int)(i % nchunk);
-        const f16x8 v = *(const f16x8*)(xb + (long)p * ldx + ch * 8);
-        f16x8 o;
+    const float* st = stat + (long)r * G * 2;
+    for (int ch = tc; ch < nchunk; ch += lanes_c) {
+        float a[8], b[8];
+        const f16x8 gm = *(const f16x8*)(gamma + ch * 8), bt = *(const f16x8*)(beta + ch * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] * sa[ch * 8 + j] + sb[ch * 8 + j];
-            if (silu) f = silu_f(f);
-            o[j] = (f16)f;
+            const int gi = (ch * 8 + j) / cpg;
+            const float mean = st[gi * 2], rstd = st[gi * 2 + 1];
+            a[j] = rstd * (float)gm[j];
+            b[j] = (float)bt[j] - mean * a[j];
         }
-        *(f16x8*)(yb + (long)p * ldy + ch * 8) = o;
+        for (int p = p0 + tp; p < p1; p += prows) {
+            const f16x8 v = *(const f16x8*)(xb + (long)p * ldx + ch * 8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = fmaf((float)v[j], a[j], b[j]);
+                if (silu) f = silu_f(f);
+                o[j] = (f16)f;
+            }
+            *(f16x8*)(yb + (long)p * ldy + ch * 8) = o;
+        }
     }
 }
 
@@ -166,7 +174,64 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* X, long ldx, f16* Y,
     }
 }
 
+// ---- row softmax in place (VAE mid-block attention scores: one head of dim C, T up to 16384) --------
+// one workgroup per row; rows up to 16384 columns stay in registers between the three phases.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(f16* X, long ld, int cols) {
+    __shared__ float red[4];
+    f16* x = X + (long)blockIdx.x * ld;
+    const int nchunk = cols >> 3;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int MAXK = 8;
+    f16x8 v[MAXK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = threadIdx.x + k * 256;
+        if (ch < nchunk) {
+            v[k] = *(const f16x8*)(x + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[k][j]);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float e[MAXK][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = threadIdx.x + k * 256;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { e[k][j] = __expf((float)v[k][j] - mx); sum += e[k][j]; }
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = threadIdx.x + k * 256;
+        if (ch < nchunk) {
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)(e[k][j] * inv);
+            *(f16x8*)(x + ch * 8) = o;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int iir_softmax_rows_f16(void* X, int64_t ld, int32_t rows, int32_t cols, void* stream) {
+    (void)hipGetLastError();
+    if (!X || rows <= 0 || cols <= 0 || cols % 8 || cols > 16384 || ld % 8) return IIR_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (f16*)X, (long)ld, cols);
+    return iir_launch_status();
+}
 
 extern "C" int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
                                       int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
@@ -175,27 +240,32 @@ extern "C" int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64
     if (!X || !Y || !gamma || !beta || !workspace) return IIR_EINVAL;
     if (C % 8 || C > GN_MAXC || groups <= 0 || groups > 64 || C % groups || ldx % 8 || ldy % 8) return IIR_EINVAL;
     if (R <= 0 || HW <= 0) return IIR_EINVAL;
-    // slabs: enough blocks to fill the chip, at least 64 pixels each
-    int nslab = (HW + 63) / 64;
-    const int want = (2048 + R - 1) / R;
+    // slabs: enough blocks to fill the chip, at least 32 pixels each
+    int nslab = (HW + 31) / 32;
+    const int want = (1024 + R - 1) / R;
     if (nslab > want) nslab = want;
     if (nslab > 256) nslab = 256;
     if (nslab < 1) nslab = 1;
     const int pps = (HW + nslab - 1) / nslab;
     nslab = (HW + pps - 1) / pps;
-    if ((int64_t)R * nslab * groups * 2 * 4 > workspace_bytes) return IIR_EINVAL;
+    const int64_t part_floats = (int64_t)R * nslab * groups * 2;
+    if ((part_floats + (int64_t)R * groups * 2) * 4 > workspace_bytes) return IIR_EINVAL;
+    float* part = (float*)workspace;
+    float* stat = part + part_floats;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, R), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, HW, C,
-                       groups, pps, (float*)workspace);
-    // apply: ~16K elements per block
-    int ppb = 16384 / C; if (ppb < 1) ppb = 1;
-    const int nblk = (HW + ppb - 1) / ppb;
+                       groups, pps, part);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, (const float*)part, nslab, groups,
+                       (float)HW * (float)(C / groups), eps, stat);
+    // apply: ~1024 blocks over the batch
+    int nblk = (1024 + R - 1) / R;
+    int ppb = (HW + nblk - 1) / nblk; if (ppb < 8) ppb = 8;
+    nblk = (HW + ppb - 1) / ppb;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, R), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, (f16*)Y,
-                       (long)ldy, HW, C, groups, ppb, (const float*)workspace, nslab, (const f16*)gamma, (const f16*)beta, eps,
-                       silu);
+                       (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
     return iir_launch_status();
 }
 
-extern "C" int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups) { return (int64_t)R * 256 * groups * 2 * 4; }
+extern "C" int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups) { return (int64_t)R * 257 * groups * 2 * 4; }
 
 extern "C" int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t rows, int32_t C, const void* gamma,
                                  const void* beta, float eps, const void* shift, const void* scale, int64_t ldmod,

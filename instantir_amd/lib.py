@@ -47,7 +47,7 @@ class ConvDesc(C.Structure):
         ("out_scale", C.c_float),
         ("tile", C.c_int32),
         ("zero_page", C.c_void_p),
-        ("x_img_stride", C.c_int64), ("y_img_rows", C.c_int32), ("res_img_rows", C.c_int32),
+        ("x_img_stride", C.c_int64), ("y_img_rows", C.c_int32), ("res_img_rows", C.c_int32), ("pad_mode", C.c_int32),
     ]
 
 
@@ -79,6 +79,7 @@ SIGNATURES = {
     "iir_groupnorm_nhwc_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _P]),
     "iir_groupnorm_workspace_bytes": (C.c_int64, [_I32, _I32]),
     "iir_layernorm_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _F, _P, _P, _I64, _I32, _I32, _I32, _I64, _P]),
+    "iir_softmax_rows_f16": (C.c_int, [_P, _I64, _I32, _I32, _P]),
     "iir_sinusoid_f16": (C.c_int, [_P, _I32, _I32, _I32, _P, _I64, _I32, _P]),
     "iir_silu_f16": (C.c_int, [_P, _P, _I64, _P]),
     "iir_copy_add_f16": (C.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _I32, _P]),

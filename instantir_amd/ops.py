@@ -124,7 +124,7 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
 
 
 def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None, rows_per_rb=1, res=None,
-           epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0, tile=0, y_img_rows=0, res_img_rows=0):
+           epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0, tile=0, y_img_rows=0, res_img_rows=0, pad_mode=0):
     """x (R,H,W,Cin) NHWC view (pixel stride x.stride(2), image stride x.stride(0) free), w (Cout,k,k,Cin) contiguous,
     out (rows, Cout[/2]) 2-D view; image i's pixels start at row i*y_img_rows (0 = dense)."""
     R, H, Wd, Cin = x.shape
@@ -148,13 +148,13 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
         _chk2d(res, "res")
         d.res, d.ldr = res.data_ptr(), res.stride(0)
     Hi, Wi = (2 * H, 2 * Wd) if upsample else (H, Wd)
-    pad = ksize // 2
-    Mo = R * ((Hi + 2 * pad - ksize) // stride + 1) * ((Wi + 2 * pad - ksize) // stride + 1)
+    pad2 = 1 if pad_mode == 1 else 2 * (ksize // 2)
+    Mo = R * ((Hi + pad2 - ksize) // stride + 1) * ((Wi + pad2 - ksize) // stride + 1)
     if tile == 0:
         tile = auto_tile(Mo, Cout)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     d.zero_page = zero_page(x.device).data_ptr()
-    d.x_img_stride, d.y_img_rows, d.res_img_rows = x.stride(0), y_img_rows, res_img_rows
+    d.x_img_stride, d.y_img_rows, d.res_img_rows, d.pad_mode = x.stride(0), y_img_rows, res_img_rows, pad_mode
     with _Timed("gemm_kernel<%s,conv>" % _TILE_NAMES[tile % 10], 2.0 * Mo * Cout * ksize * ksize * Cin):
         L.check(L.load().iir_conv2d_nhwc_f16(C.byref(d), _stream()), "iir_conv2d_nhwc_f16")
     return out
@@ -300,3 +300,10 @@ def axpby_f32(x, y, coef, out):
 def prefetch(ptr, nbytes, blocks=32):
     """Pull [ptr, ptr+nbytes) towards the Infinity Cache on the current stream."""
     L.check(L.load().iir_prefetch(ptr, nbytes, blocks, _stream()), "iir_prefetch")
+
+
+def softmax_rows(x):
+    """In-place softmax over the columns of a 2-D fp16 view (cols <= 16384)."""
+    _chk2d(x, "x")
+    L.check(L.load().iir_softmax_rows_f16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], _stream()), "iir_softmax_rows_f16")
+    return x

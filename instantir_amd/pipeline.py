@@ -163,6 +163,23 @@ class InstantIRPipeline:
                 raise ValueError("`ip_adapter_image_embeds` has to be a list of 3D or 4D tensors but is "
                                  f"{ip_adapter_image_embeds[0].ndim}D")
 
+    @staticmethod
+    def _prepare_image(image):
+        """`prepare_image` (:905-929) via VaeImageProcessor(do_normalize=True): PIL / numpy / [0,1] tensors
+        become fp32 NCHW in [-1,1]; 4-channel tensors (latents) and tensors already below 0 pass through."""
+        if torch.is_tensor(image):
+            if image.shape[1] == 4 or image.min() < 0:
+                return image
+            return image * 2.0 - 1.0
+        import numpy as np
+        if not isinstance(image, (list, tuple)):
+            image = [image]
+        arrs = [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.float32) / 255.0 for im in image]
+        x = torch.from_numpy(np.stack(arrs)).permute(0, 3, 1, 2)
+        if x.shape[2] % 8 or x.shape[3] % 8:
+            raise ValueError(f"image size {tuple(x.shape[2:])} must be a multiple of 8 (infer.py:31-66 resizes to multiples of 64)")
+        return x * 2.0 - 1.0
+
     # ---- the call ---------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, prompt=None, prompt_2=None, image=None, height=None, width=None, num_inference_steps: int = 30,
@@ -197,11 +214,13 @@ class InstantIRPipeline:
         self._build()
 
         B = prompt_embeds.shape[0] * num_images_per_prompt
-        assert B == len(image) or len(image) == 1                                 # :1316-1319
-        if image.shape[1] != 4:
+        n_img = 1 if hasattr(image, "size") and not torch.is_tensor(image) and not isinstance(image, (list, tuple)) else len(image)
+        assert B == n_img or n_img == 1                                           # :1316-1319
+        image = self._prepare_image(image)
+        if image.shape[1] != 4:                                                        # :1369-1379
             if self.vae is None:
                 raise NotImplementedError("pixel-space `image` needs a VAE; pass the LQ latent (B,4,h,w)")
-            image = self.vae.encode_to_latent(image)
+            image = self.vae.encode_to_latent(image, eps=kwargs.get("vae_noise"), generator=None)
         lq = image.to(dev, torch.float32)
         if lq.shape[0] == 1 and B > 1:
             lq = lq.repeat(B, 1, 1, 1)

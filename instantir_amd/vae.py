@@ -1,0 +1,229 @@
+"""SDXL AutoencoderKL on MI355X: decode (latents -> image) and encode (image -> LQ latent).
+
+Reference call sites: `pipelines/sdxl_instantir.py:1370-1379` (encode + `latent_dist.sample()` x
+scaling_factor) and `:1668-1695` (`latents / scaling_factor` -> `vae.decode`), run there in fp32 after
+`upcast_vae` (:984-1001) because the SDXL VAE overflows fp16.  Spec text: `module/diffusers_vae/vae.py:46-350`,
+`:771-793`.  Here: fp16 storage, fp32 accumulation and fp32 GroupNorm statistics -- adequate for the
+seeded synthetic weights this build can test with; real SDXL-VAE weights need the bf16 variant of the same
+kernels and are NOT validated.
+
+Kernels reused from the UNet path (NHWC): implicit-GEMM conv (3x3, 1x1, nearest-2x folded, the
+encoder's bottom/right-padded stride-2 conv), GroupNorm+SiLU, GEMM.  The single-head d = C attention of
+the mid block is three GEMMs around an in-place row softmax (`iir_softmax_rows_f16`): S = QK^T/sqrt(C),
+P = softmax(S), O = P V + b_v (rows of P sum to 1, so the V bias is added after the product).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import ops
+from .config import VAEConfig
+from .engine import CPAD, F16, Arena, _NullOps
+from .packing import conv_weight_nhwc
+
+
+class HipVAE:
+    def __init__(self, cfg: VAEConfig, sd: Dict[str, torch.Tensor], device):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.w: Dict[str, torch.Tensor] = {}
+        self.arena = Arena(self.device)
+        self.o = ops
+        self._gnws = ops.gn_workspace(self.device, 64, cfg.norm_groups)
+        self._sized = {}
+        self.has_decoder = "decoder.conv_in.weight" in sd
+        self.has_encoder = "encoder.conv_in.weight" in sd
+        t = lambda n: sd[n].to(device=self.device, dtype=F16)
+        for name in sd:
+            if not name.endswith(".weight"):
+                continue
+            p = name[: -len(".weight")]
+            w = t(name)
+            if w.dim() == 4:
+                cin_pad = CPAD if w.shape[1] < CPAD else None          # 3/4/8-channel inputs are zero-padded to one K tile
+                if w.shape[2] == 1:
+                    k = w.reshape(w.shape[0], w.shape[1])
+                    if cin_pad:
+                        k = torch.nn.functional.pad(k, (0, cin_pad - k.shape[1]))
+                    self.w[p + ".w"] = k.contiguous()
+                else:
+                    self.w[p + ".w"] = conv_weight_nhwc(w, cin_pad)
+                b = t(p + ".bias")
+                if w.shape[0] % 4:                                         # conv_out: 3 output channels -> 4
+                    padn = 4 - w.shape[0] % 4
+                    self.w[p + ".w"] = torch.cat([self.w[p + ".w"], torch.zeros(padn, *self.w[p + ".w"].shape[1:], dtype=F16, device=self.device)]).contiguous()
+                    b = torch.cat([b, torch.zeros(padn, dtype=F16, device=self.device)])
+                self.w[p + ".b"] = b.contiguous()
+            elif w.dim() == 2:
+                self.w[p + ".w"] = w.contiguous()
+                self.w[p + ".b"] = t(p + ".bias").contiguous()
+            else:
+                self.w[p + ".g"] = w.contiguous()
+                self.w[p + ".b"] = t(p + ".bias").contiguous()
+
+    # ---- blocks -----------------------------------------------------------------------------------
+    def _resnet(self, path, x, R, H, W):
+        """ResnetBlock2D without temb, GN eps 1e-6 (module/diffusers_vae/vae.py:241-252 via blocks :2804-2874)."""
+        o, w, A, g = self.o, self.w, self.arena, self.cfg.norm_groups
+        HW, cin = H * W, x.shape[1]
+        cout = w[path + ".conv1.w"].shape[0]
+        out = A.alloc(R * HW, cout)
+        m = A.mark()
+        h = A.alloc(R * HW, cin)
+        o.groupnorm(x, h, R, HW, w[path + ".norm1.g"], w[path + ".norm1.b"], 1e-6, True, g, self._gnws)
+        h2 = A.alloc(R * HW, cout)
+        o.conv2d(h.view(R, H, W, cin), w[path + ".conv1.w"], h2, bias=w[path + ".conv1.b"])
+        h3 = A.alloc(R * HW, cout)
+        o.groupnorm(h2, h3, R, HW, w[path + ".norm2.g"], w[path + ".norm2.b"], 1e-6, True, g, self._gnws)
+        if (path + ".conv_shortcut.w") in w:
+            sc = A.alloc(R * HW, cout)
+            o.gemm(x, w[path + ".conv_shortcut.w"], sc, bias=w[path + ".conv_shortcut.b"])
+        else:
+            sc = x
+        o.conv2d(h3.view(R, H, W, cout), w[path + ".conv2.w"], out, bias=w[path + ".conv2.b"], res=sc)
+        A.release(m)
+        return out
+
+    def _attention(self, path, x, R, H, W):
+        """Attention(heads=1, dim_head=C, group_norm, bias, residual) -- blocks :776-790, processor :346-412."""
+        o, w, A = self.o, self.w, self.arena
+        T, C = H * W, x.shape[1]
+        out = A.alloc(R * T, C)
+        m = A.mark()
+        n = A.alloc(R * T, C)
+        o.groupnorm(x, n, R, T, w[path + ".group_norm.g"], w[path + ".group_norm.b"], 1e-6, False, self.cfg.norm_groups, self._gnws)
+        q, k = A.alloc(R * T, C), A.alloc(R * T, C)
+        o.gemm(n, w[path + ".to_q.w"], q, bias=w[path + ".to_q.b"])
+        o.gemm(n, w[path + ".to_k.w"], k, bias=w[path + ".to_k.b"])
+        a = A.alloc(R * T, C)
+        s = A.alloc(T, T)
+        vt = A.alloc(C, T)
+        for r in range(R):
+            rows = slice(r * T, (r + 1) * T)
+            o.gemm(w[path + ".to_v.w"], n[rows], vt)                               # V^T (bias added after P V)
+            o.gemm(q[rows], k[rows], s, out_scale=C ** -0.5)                      # S = Q K^T / sqrt(C)
+            o.softmax_rows(s)
+            o.gemm(s, vt, a[rows], bias=w[path + ".to_v.b"])                      # O = P V + b_v
+        o.gemm(a, w[path + ".to_out.0.w"], out, bias=w[path + ".to_out.0.b"], res=x)
+        A.release(m)
+        return out
+
+    def _mid(self, path, x, R, H, W):
+        x = self._resnet(path + ".resnets.0", x, R, H, W)
+        x = self._attention(path + ".attentions.0", x, R, H, W)
+        return self._resnet(path + ".resnets.1", x, R, H, W)
+
+    def _run(self, key, fn):
+        if key not in self._sized:
+            self.arena.buf, self.arena.off, self.arena.high = None, 0, 0
+            self.o = _NullOps()
+            try:
+                fn()
+            finally:
+                self.o = ops
+            self._sized[key] = self.arena.high + 1024
+        need = max(self._sized.values())
+        if self.arena.buf is None or self.arena.buf.numel() < need:
+            self.arena.reserve(need)
+        self.arena.reset()
+        return fn()
+
+    # ---- decode -----------------------------------------------------------------------------------
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """z: (B,4,h,w) fp32 latents ALREADY divided by the scaling factor.  Returns (B,3,8h,8w) fp32."""
+        z = z.to(self.device, torch.float32).contiguous()
+        B, _, h, wd = z.shape
+        out = torch.empty(B, 4, 8 * h, 8 * wd, dtype=torch.float32, device=self.device)
+        zin = torch.zeros(B * h * wd, CPAD, dtype=F16, device=self.device)
+        ops.pack_latent(z, zin)
+        self._run(("dec", B, h, wd), lambda: self._decode(zin, B, h, wd, out))
+        return out[:, :3]
+
+    def _decode(self, zin, R, H, W, out):
+        o, w, A, cfg = self.o, self.w, self.arena, self.cfg
+        ch = list(reversed(cfg.block_out_channels))
+        x0 = A.alloc(R * H * W, CPAD)
+        if self.o is ops:
+            x0.zero_()
+        pq = x0[:, :4]
+        o.gemm(zin, w["post_quant_conv.w"], pq, bias=w["post_quant_conv.b"])                   # 1x1, 4 -> 4
+        x = A.alloc(R * H * W, ch[0])
+        o.conv2d(x0.view(R, H, W, CPAD), w["decoder.conv_in.w"], x, bias=w["decoder.conv_in.b"])
+        x = self._mid("decoder.mid_block", x, R, H, W)
+        for i, c in enumerate(ch):
+            for j in range(cfg.layers_per_block + 1):
+                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, R, H, W)
+            if i < len(ch) - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                y = A.alloc(R * 4 * H * W, c)
+                o.conv2d(x.view(R, H, W, c), w[p + ".w"], y, upsample=True, bias=w[p + ".b"])
+                x, H, W = y, 2 * H, 2 * W
+        g = A.alloc(R * H * W, ch[-1])
+        o.groupnorm(x, g, R, H * W, w["decoder.conv_norm_out.g"], w["decoder.conv_norm_out.b"], 1e-6, True, cfg.norm_groups, self._gnws)
+        img = A.alloc(R * H * W, 4)
+        o.conv2d(g.view(R, H, W, ch[-1]), w["decoder.conv_out.w"], img, bias=w["decoder.conv_out.b"])
+        o.unpack_latent(img, out)
+        return out
+
+    def decode_latent(self, latents: torch.Tensor, output_type: str = "pt"):
+        """pipelines/sdxl_instantir.py:1689-1704: latents / scaling_factor -> decode -> postprocess
+        (VaeImageProcessor: (x / 2 + 0.5).clamp(0, 1); 'pt' tensor, 'np' NHWC array, 'pil' images)."""
+        img = self.decode(latents.to(self.device, torch.float32) / self.cfg.scaling_factor)
+        img = (img / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return img
+        arr = img.permute(0, 2, 3, 1).cpu().numpy()
+        if output_type == "np":
+            return arr
+        if output_type == "pil":
+            from PIL import Image
+            return [Image.fromarray((a * 255).round().astype("uint8")) for a in arr]
+        raise ValueError(f"unknown output_type {output_type}")
+
+    # ---- encode -----------------------------------------------------------------------------------
+    def encode(self, image: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+        """image (B,3,H,W) in [-1,1]; eps (B,4,H/8,W/8) the N(0,1) draw of `latent_dist.sample()`.
+        Returns the UNscaled latent mean + std * eps (fp32)."""
+        image = image.to(self.device, torch.float32).contiguous()
+        B, _, H, W = image.shape
+        xin = torch.zeros(B * H * W, CPAD, dtype=F16, device=self.device)
+        ops.pack_latent(image, xin)
+        mom = torch.empty(B, 8, H // 8, W // 8, dtype=torch.float32, device=self.device)
+        self._run(("enc", B, H, W), lambda: self._encode(xin, B, H, W, mom))
+        mean, logvar = mom[:, :4], mom[:, 4:]
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))           # module/diffusers_vae/vae.py:774-777,792
+        return mean + std * eps.to(self.device, torch.float32)
+
+    def encode_to_latent(self, image, eps=None, generator=None):
+        """`vae.encode(image).latent_dist.sample() * scaling_factor` (pipelines/sdxl_instantir.py:1375-1376)."""
+        B, _, H, W = image.shape
+        if eps is None:
+            gdev = generator.device if generator is not None else self.device
+            eps = torch.randn(B, 4, H // 8, W // 8, generator=generator, device=gdev, dtype=torch.float32)
+        return self.encode(image, eps) * self.cfg.scaling_factor
+
+    def _encode(self, xin, R, H, W, mom):
+        o, w, A, cfg = self.o, self.w, self.arena, self.cfg
+        ch = list(cfg.block_out_channels)
+        x = A.alloc(R * H * W, ch[0])
+        o.conv2d(xin.view(R, H, W, CPAD), w["encoder.conv_in.w"], x, bias=w["encoder.conv_in.b"])
+        for i, c in enumerate(ch):
+            for j in range(cfg.layers_per_block):
+                x = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", x, R, H, W)
+            if i < len(ch) - 1:
+                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                y = A.alloc(R * (H // 2) * (W // 2), c)
+                o.conv2d(x.view(R, H, W, c), w[p + ".w"], y, stride=2, pad_mode=1, bias=w[p + ".b"])   # F.pad(0,1,0,1) + conv s2 p0
+                x, H, W = y, H // 2, W // 2
+        x = self._mid("encoder.mid_block", x, R, H, W)
+        g = A.alloc(R * H * W, ch[-1])
+        o.groupnorm(x, g, R, H * W, w["encoder.conv_norm_out.g"], w["encoder.conv_norm_out.b"], 1e-6, True, cfg.norm_groups, self._gnws)
+        m8 = A.alloc(R * H * W, CPAD)
+        if self.o is ops:
+            m8.zero_()
+        o.conv2d(g.view(R, H, W, ch[-1]), w["encoder.conv_out.w"], m8[:, :8], bias=w["encoder.conv_out.b"])
+        q8 = A.alloc(R * H * W, 8)
+        o.gemm(m8, w["quant_conv.w"], q8, bias=w["quant_conv.b"])                                  # 1x1, 8 -> 8
+        o.unpack_latent(q8, mom)
+        return mom

@@ -238,6 +238,31 @@ def vae_decoder_specs(cfg: VAEConfig) -> List[Spec]:
     return specs
 
 
+def vae_encoder_specs(cfg: VAEConfig) -> List[Spec]:
+    """AutoencoderKL Encoder + quant_conv (module/diffusers_vae/vae.py:46-195)."""
+    specs: List[Spec] = []
+    ch = list(cfg.block_out_channels)
+    _conv(specs, "encoder.conv_in", cfg.in_channels, ch[0], 3)
+    prev = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            _vae_resnet(specs, f"encoder.down_blocks.{i}.resnets.{j}", prev, c)
+            prev = c
+        if i < len(ch) - 1:
+            _conv(specs, f"encoder.down_blocks.{i}.downsamplers.0.conv", c, c, 3)
+    _vae_resnet(specs, "encoder.mid_block.resnets.0", prev, prev)
+    a = "encoder.mid_block.attentions.0"
+    _norm(specs, a + ".group_norm", prev)
+    for n in ("to_q", "to_k", "to_v"):
+        _lin(specs, f"{a}.{n}", prev, prev)
+    _lin(specs, a + ".to_out.0", prev, prev, kind="wo")
+    _vae_resnet(specs, "encoder.mid_block.resnets.1", prev, prev)
+    _norm(specs, "encoder.conv_norm_out", prev)
+    _conv(specs, "encoder.conv_out", prev, 2 * cfg.latent_channels, 3)
+    _conv(specs, "quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    return specs
+
+
 def _vae_resnet(specs, path, cin, cout):
     _norm(specs, path + ".norm1", cin)
     _conv(specs, path + ".conv1", cin, cout, 3)
