@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--prefetch", action="store_true", help="enable the side-stream weight prefetcher (experimental)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no encoder/previewer overlap)")
     args = ap.parse_args()
@@ -145,6 +146,25 @@ def main():
     finite = bool(torch.isfinite(x).all().item())
     log(f"timed: {dt / args.steps * 1e3:.2f} ms/step")
 
+    # ---- VAE legs (once per image, outside the step metric): full SDXL VAE geometry ----------------------
+    vae_ms = None
+    if rank == 0 and not args.tiny and not args.no_vae:
+        from instantir_amd.config import VAEConfig
+        from instantir_amd.vae import HipVAE
+        vc = VAEConfig.sdxl()
+        hv = HipVAE(vc, W.synth_state_dict(W.vae_decoder_specs(vc) + W.vae_encoder_specs(vc), seed + 3, device=dev), dev)
+        px_img = torch.rand(1, 3, px, px, generator=g) * 2 - 1
+        eps_l = torch.randn(1, 4, Hl, Hl, generator=g)
+        for _ in range(2):
+            hv.decode(x / vc.scaling_factor); hv.encode(px_img, eps_l)
+        torch.cuda.synchronize()
+        tv = time.perf_counter(); hv.decode(x / vc.scaling_factor); torch.cuda.synchronize(); dec_ms = (time.perf_counter() - tv) * 1e3
+        tv = time.perf_counter(); hv.encode(px_img, eps_l); torch.cuda.synchronize(); enc_ms = (time.perf_counter() - tv) * 1e3
+        vae_ms = {"decode_ms": round(dec_ms, 2), "encode_ms": round(enc_ms, 2)}
+        log(f"vae decode {dec_ms:.1f} ms, encode {enc_ms:.1f} ms")
+        del hv
+        torch.cuda.empty_cache()
+
     # ---- roofline leg: eager, every MFMA launch bracketed by HIP events --------------------------
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -192,7 +212,8 @@ def main():
                                    + (" [TINY DEBUG GEOMETRY]" if args.tiny else ""),
                        "images_per_gpu": B, "latent": [Hl, Hl], "params": n_params, "graph": not args.no_graph,
                        "step_tflop_model": STEP_TFLOP, "model_tflops_per_gpu": round(STEP_TFLOP * args.steps / dt, 1),
-                       "images_per_s_30step_est": round(world * args.steps / dt / 30, 4), "finite": finite,
+                       "images_per_s_30step": round(world / (30 * dt / args.steps + (((vae_ms or {}).get("decode_ms", 0) + (vae_ms or {}).get("encode_ms", 0)) * 1e-3)), 4),
+                       "vae": vae_ms, "finite": finite,
                        "setup_s": round(setup_s, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }

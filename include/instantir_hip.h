@@ -47,7 +47,7 @@ typedef struct iir_gemm_desc {
     const void* res; int64_t ldr;  /* residual / SFT `h` input, or NULL                            */
     int32_t epi, act;
     float out_scale;               /* 0 means 1                                                    */
-    int32_t tile;                  /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64                   */
+    int32_t tile;                  /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x160, 5 = 64x160 */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -55,6 +55,8 @@ typedef struct iir_gemm_desc {
  * feed-forward module/min_sdxl.py:502-528; proj_in/out :572,575; time_emb_proj :266; embeddings
  * :226-240; AdaLayerNorm linear attention_processor.py:23; Resampler resampler.py:48-49,66-68,95-97. */
 int iir_gemm_f16(const iir_gemm_desc* d, void* stream);
+/* the tile `tile = 0` resolves to for an (M, N) problem (paired != 0 for GEGLU / SFT epilogues) */
+int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t paired);
 
 typedef struct iir_conv_desc {
     const void* X; int64_t ldx;    /* NHWC input (R, H, W, Cin), pixel stride ldx >= Cin           */

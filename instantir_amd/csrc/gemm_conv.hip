@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 for (int t = 0; t < 4; ++t) o[t] = (f16)(v[t] * g.out_scale);
                 *(f16x4*)(g.C + mc * g.ldc + n) = o;
             }
-        } else {
+        } else if constexpr (NI % 2 == 0) {
             // paired columns: in every 32-column group of the (row-permuted) weight the first 16 are
             // the "value" rows and the next 16 their partners (gate for GEGLU; beta for SFT).
 #pragma unroll
@@ -277,30 +277,47 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
     return iir_launch_status();
 }
 
-int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
-    // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64}; t + 10*stages selects the LDS ring depth.
-    if (tile == 0) {
-        auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
-        if (blocks(128, 128) >= IIR_T1_MIN) tile = 1;
-        else if (blocks(128, 64) >= IIR_T2_MIN) tile = 2;
-        else tile = 3;
+struct TileShape { int bm, bn; };
+constexpr TileShape kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
+
+// Tile choice: the per-CU operand fill rate (L2 -> LDS, ~50-70 GB/s) bounds these launches, so pick the
+// shape that minimises the bytes the busiest CU has to pull.  Two workgroups per CU overlap each other's
+// load latency, so capacity is counted in 512 slots: cost = ceil(blocks / 512) * 2 * (BM + BN) [* K * 2 B].
+int pick_tile(int M, int N, bool paired) {
+    long best = -1;
+    int pick = 1;
+    for (int t = 1; t <= 5; ++t) {
+        if (paired && (kTiles[t].bn / 32) % 2) continue;            // paired epilogues need an even tile count per wave
+        const long blocks = (long)((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((N + kTiles[t].bn - 1) / kTiles[t].bn);
+        const long cost = ((blocks + 511) / 512) * 2 * (kTiles[t].bm + kTiles[t].bn);
+        if (best < 0 || cost < best || (cost == best && kTiles[t].bm * kTiles[t].bn > kTiles[pick].bm * kTiles[pick].bn)) {
+            best = cost;
+            pick = t;
+        }
     }
+    return pick;
+}
+
+int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
+    // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64, 4: 128x160, 5: 64x160}; t + 10*stages selects the ring depth.
+    if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN);
     if (tile < 10) tile += 10 * IIR_DEFAULT_STAGES;
     switch (tile) {
         case 21: return launch<128, 128, 2>(g, conv, stream);
         case 31: return launch<128, 128, 3>(g, conv, stream);
-        case 41: return launch<128, 128, 4>(g, conv, stream);
         case 22: return launch<128, 64, 2>(g, conv, stream);
         case 32: return launch<128, 64, 3>(g, conv, stream);
-        case 42: return launch<128, 64, 4>(g, conv, stream);
         case 23: return launch<64, 64, 2>(g, conv, stream);
         case 33: return launch<64, 64, 3>(g, conv, stream);
-        case 43: return launch<64, 64, 4>(g, conv, stream);
+        case 24: return launch<128, 160, 2>(g, conv, stream);
+        case 25: return launch<64, 160, 2>(g, conv, stream);
         default: return IIR_EINVAL;
     }
 }
 
 }  // namespace
+
+extern "C" int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t paired) { return pick_tile(M, N, paired != 0); }
 
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     (void)hipGetLastError();
@@ -308,6 +325,7 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % BK) return IIR_EINVAL;
     if (d->N % 4 || d->lda % 8 || d->ldc % 4) return IIR_EINVAL;
     if (d->epi != IIR_EPI_PLAIN && (d->N % 32)) return IIR_EINVAL;
+    if (d->epi != IIR_EPI_PLAIN && (d->tile % 10 == 4 || d->tile % 10 == 5)) return IIR_EINVAL;
     if (d->epi == IIR_EPI_SFT && !d->res) return IIR_EINVAL;
     if (d->rowbias && d->rows_per_rb <= 0) return IIR_EINVAL;
     Geo g{};
@@ -327,6 +345,7 @@ extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
     if (c->stride != 1 && c->stride != 2) return IIR_EINVAL;
     if (c->upsample && c->stride != 1) return IIR_EINVAL;
     if (c->epi != IIR_EPI_PLAIN && (c->Cout % 32)) return IIR_EINVAL;
+    if (c->epi != IIR_EPI_PLAIN && (c->tile % 10 == 4 || c->tile % 10 == 5)) return IIR_EINVAL;
     if (c->epi == IIR_EPI_SFT && !c->res) return IIR_EINVAL;
     if (c->rowbias && c->rows_per_rb <= 0) return IIR_EINVAL;
     const int pad = c->pad_mode == 1 ? 0 : c->ksize / 2;   // mode 1: taps reach 1 pixel past the bottom/right edge only

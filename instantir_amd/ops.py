@@ -47,22 +47,12 @@ class LaunchProfiler:
 
 PROFILER = None     # set to a LaunchProfiler to time gemm / conv / attention launches
 
-_TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64"}
+_TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x160", 5: "64x160"}
 
 
-import os as _os
-T1_MIN = int(_os.environ.get("IIR_T1_MIN", 384))
-T2_MIN = int(_os.environ.get("IIR_T2_MIN", 256))
-
-
-def auto_tile(M, N):
-    """Same rule as `dispatch()` in csrc/gemm_conv.hip (kept in sync so profiles can name the kernel)."""
-    blocks = lambda bm, bn: ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-    if blocks(128, 128) >= T1_MIN:
-        return 1
-    if blocks(128, 64) >= T2_MIN:
-        return 2
-    return 3
+def auto_tile(M, N, paired=False):
+    """The tile `tile=0` resolves to (single source of truth: pick_tile() in csrc/gemm_conv.hip)."""
+    return L.load().iir_gemm_pick_tile(M, N, int(paired))
 
 
 class _Timed:
@@ -116,7 +106,7 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
         _chk2d(res, "res")
         d.res, d.ldr = res.data_ptr(), res.stride(0)
     if tile == 0:
-        tile = auto_tile(M, N)
+        tile = auto_tile(M, N, epi != EPI_PLAIN)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile % 10], 2.0 * M * N * K):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
@@ -151,7 +141,7 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     pad2 = 1 if pad_mode == 1 else 2 * (ksize // 2)
     Mo = R * ((Hi + pad2 - ksize) // stride + 1) * ((Wi + pad2 - ksize) // stride + 1)
     if tile == 0:
-        tile = auto_tile(Mo, Cout)
+        tile = auto_tile(Mo, Cout, epi != EPI_PLAIN)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     d.zero_page = zero_page(x.device).data_ptr()
     d.x_img_stride, d.y_img_rows, d.res_img_rows, d.pad_mode = x.stride(0), y_img_rows, res_img_rows, pad_mode
