@@ -1,0 +1,72 @@
+"""GPU parity at FULL SDXL / InstantIR shapes -- BASELINE.json configs[0]: single 512x512 input, 4-step DDIM,
+cfg = 1.0 (no CFG doubling), CPU fp32 oracle vs the HIP path, seeded synthetic weights (4.4 B parameters).
+The north-star tolerance is latent PSNR >= 50 dB at fp16.  Takes ~1-2 minutes (CPU oracle on the box's cores)."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+@pytest.mark.parametrize("guidance,steps", [(1.0, 4), (7.0, 3)])
+def test_config0_512px_full_sdxl_shapes(guidance, steps):
+    """(1.0, 4) is BASELINE configs[0]; (7.0, 3) adds the CFG-doubled batch (2 rows) of configs[1] at 512 px."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from instantir_amd import lib, weights as W
+    from instantir_amd.config import UNetConfig
+    from instantir_amd.pipeline import InstantIRPipeline
+    from instantir_amd.schedulers import DDIMScheduler, LCMSingleStepScheduler
+    from oracle import pipeline as OP
+    lib.load()
+    dev = torch.device("cuda:0")
+    cfg = UNetConfig.sdxl()
+    sd = W.synth_state_dict(W.unet_specs(cfg), 1234, device=dev)
+    sda = W.synth_state_dict(W.aggregator_specs(cfg), 1235, device=dev)
+    lora = W.synth_state_dict(W.lora_specs(cfg), 1236, device=dev)
+    g = torch.Generator().manual_seed(42)
+    B, H = 1, 64
+    lq = torch.randn(B, 4, H, H, generator=g) * 0.8
+    pe = torch.randn(B, 77, 2048, generator=g).half().float()
+    pooled = torch.randn(B, 1280, generator=g).half().float()
+    feats = torch.randn(2 if guidance > 1 else 1, B, 257, 1024, generator=g).half().float()
+    npe = torch.randn(B, 77, 2048, generator=g).half().float()
+    npooled = torch.randn(B, 1280, generator=g).half().float()
+    noise = torch.randn(B, 4, H, H, generator=g)
+    alpha = 8
+    pipe = InstantIRPipeline(cfg, sd, scheduler=DDIMScheduler(), device=dev)
+    pipe.aggregator.load_state_dict(sda)
+    pipe.prepare_previewers(lora, lora_alpha=alpha)
+    got = pipe(image=lq, prompt_embeds=pe, pooled_prompt_embeds=pooled, negative_prompt_embeds=npe,
+               negative_pooled_prompt_embeds=npooled, ip_adapter_image_embeds=[feats], output_type="latent",
+               num_inference_steps=steps, guidance_scale=guidance, init_noise=noise,
+               previewer_scheduler=LCMSingleStepScheduler.from_config(pipe.scheduler.config)).images.float().cpu()
+    assert torch.isfinite(got).all()
+    # CPU oracle on the same (fp16-rounded) weights
+    torch.set_num_threads(_host_cores())
+    P = {k: v.float().cpu() for k, v in sd.items()}
+    PA = {k: v.float().cpu() for k, v in sda.items()}
+    L = {k: v.float().cpu() for k, v in lora.items()}
+    L["scaling"] = alpha / cfg.lora_rank
+    del sd, sda, lora, pipe
+    torch.cuda.empty_cache()
+    with torch.no_grad():
+        want = OP.denoise(P, PA, L, cfg, lq, pe, pooled, feats, negative_prompt_embeds=npe, negative_pooled=npooled,
+                          init_noise=noise, num_inference_steps=steps, guidance_scale=guidance, sampler="ddim")
+    mse = ((got - want) ** 2).mean().item()
+    p = 10 * math.log10(want.abs().max().item() ** 2 / max(mse, 1e-30))
+    print(f"full-shape 512px cfg={guidance} steps={steps}: latent PSNR vs CPU fp32 oracle {p:.1f} dB")
+    assert p >= 50.0, p
