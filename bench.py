@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--prefetch", action="store_true", help="enable the side-stream weight prefetcher (experimental)")
+    ap.add_argument("--no-inkernel-prefetch", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no encoder/previewer overlap)")
     args = ap.parse_args()
 
@@ -98,6 +99,7 @@ def main():
     pipe._build()
     for net in (pipe._unet, pipe._unet_prev, pipe._agg):
         net.prefetch = args.prefetch
+        net.inkernel_prefetch = not args.no_inkernel_prefetch
     log(f"engines built ({time.time() - t0:.1f} s)")
     n_params = sum(v.numel() for v in sd.values()) + sum(v.numel() for v in sda.values())
     cpu_sd = None

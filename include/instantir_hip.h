@@ -48,6 +48,8 @@ typedef struct iir_gemm_desc {
     int32_t epi, act;
     float out_scale;               /* 0 means 1                                                    */
     int32_t tile;                  /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x160, 5 = 64x160 */
+    const void* prefetch;          /* optional: range the workgroups touch after their K loop so it is   */
+    int64_t prefetch_bytes;        /*   in the Infinity Cache for a LATER launch (next layers' weights)   */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -76,6 +78,8 @@ typedef struct iir_conv_desc {
     int32_t res_img_rows;          /* rows between images in res; 0 = Ho*Wo                        */
     int32_t pad_mode;              /* 0: symmetric ksize/2; 1: pad 0 top/left, 1 bottom/right (VAE  */
                                    /*    Downsample2D(padding=0) + F.pad(0,1,0,1), vae.py:110)      */
+    const void* prefetch;          /* as in iir_gemm_desc                                          */
+    int64_t prefetch_bytes;
 } iir_conv_desc;
 
 /* Replaces nn.Conv2d call sites: ResnetBlock2D module/min_sdxl.py:256-259,274 (+ the temb add :267 as

@@ -48,6 +48,7 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     int y_img_rows, res_img_rows;   // rows between images in C / res (conv mode); 0 = dense
     int tiles_m, tiles_n;
     int xm, rm, rn;           // XCD partition: xm x (8/xm) rectangles of rm x rn tiles
+    const char* pf; int pf_lines;   // weight prefetch: 128-byte lines to pull towards the Infinity Cache
 };
 
 constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
@@ -194,6 +195,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
         nxt = nxt + 1 == ST ? 0 : nxt + 1;
     }
 
+    // ---- weight prefetch for the launches that follow (see iir_gemm_desc.prefetch): every workgroup touches
+    // its slice of the range with 4-byte LDS-DMA loads (no VGPR destination, so nothing the epilogue uses can be
+    // clobbered by a late return); the data lands in a scratch KiB behind the ring and is never read.
+    if (g.pf_lines > 0) {
+        const int per = (g.pf_lines + (int)gridDim.x - 1) / (int)gridDim.x;
+        const long l0 = (long)blockIdx.x * per;
+        char* scratch = smem + ST * (BM + BN) * BK * (int)sizeof(f16) + wave * 256;
+        for (int i = lane + wave * 64; i < per; i += 256) {
+            long l = l0 + i;
+            if (l >= g.pf_lines) l = g.pf_lines - 1;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(g.pf + l * 128), (LDS_AS void*)scratch, 4, 0, 0);
+        }
+    }
+
     // ---- epilogue: lane holds row m = ..+frow, 4 consecutive columns n = ..+4*fq+{0..3} ---------
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
             }
         }
     }
+    if (g.pf_lines > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA must land before the LDS is released
 }
 
 template <int BM, int BN, int ST>
@@ -253,7 +269,7 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = ST * (BM + BN) * BK * sizeof(f16);
+    const size_t lds = ST * (BM + BN) * BK * sizeof(f16) + 1024;   // + prefetch scratch
     // pick the XCD partition with the least per-L2 operand rows: (tiles_m/xm)*BM + (tiles_n/xn)*BN
     long best = -1;
     static const int force_xm = getenv("IIR_XM") ? atoi(getenv("IIR_XM")) : 0;   // tuning knob: 1,2,4,8 forces the split
@@ -334,6 +350,7 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     g.bias = (const f16*)d->bias; g.rowbias = (const f16*)d->rowbias; g.ldrb = d->ldrb; g.rows_per_rb = d->rows_per_rb;
     g.res = (const f16*)d->res; g.ldr = d->ldr; g.epi = d->epi; g.act = d->act;
     g.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
+    g.pf = (const char*)d->prefetch; g.pf_lines = d->prefetch ? (int)(d->prefetch_bytes / 128) : 0;
     return dispatch(g, false, d->tile, (hipStream_t)stream);
 }
 
@@ -361,6 +378,7 @@ extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
     g.out_scale = c->out_scale == 0.f ? 1.f : c->out_scale;
     g.H = c->H; g.Wd = c->Wd; g.Cin = c->Cin; g.ks = c->ksize; g.stride = c->stride; g.pad = pad; g.ups = c->upsample;
     g.zero = (const f16*)c->zero_page;
+    g.pf = (const char*)c->prefetch; g.pf_lines = c->prefetch ? (int)(c->prefetch_bytes / 128) : 0;
     g.x_img_stride = c->x_img_stride ? c->x_img_stride : (int64_t)c->H * c->Wd * c->ldx;
     g.y_img_rows = c->y_img_rows; g.res_img_rows = c->res_img_rows;
     return dispatch(g, true, c->tile, (hipStream_t)stream);

@@ -136,6 +136,8 @@ class _Net:
         self._pf_stream = None
         self._pf_forked = False
         self._gnws = None
+        self._warena = None
+        self.inkernel_prefetch = True
         self._pack_encoder(sd)
 
     # ---- weight packing ---------------------------------------------------------------------
@@ -306,6 +308,22 @@ class _Net:
             ops.prefetch(self.units[k + 1][0], self.units[k + 1][1], PREFETCH_BLOCKS)
         self._pf_forked = True
 
+    import os as _os
+    PF_MULT = float(_os.environ.get("IIR_PF_MULT", "1"))
+    PF_LOOKAHEAD = int(_os.environ.get("IIR_PF_MB", "0")) << 20      # bytes of weight arena between a launch's own weights and what it prefetches
+
+    def _pf(self, wt):
+        """(ptr, bytes) of the weight-arena range a launch using `wt` should pull towards the Infinity Cache:
+        as many bytes as it consumes itself, PF_LOOKAHEAD further along the (execution-ordered) arena."""
+        if not self.inkernel_prefetch or self._warena is None or self.o is not ops:
+            return None
+        base, end = self._warena.data_ptr(), self._warena.data_ptr() + self._warena.numel() * 2
+        n = wt.numel() * 2
+        lo = wt.data_ptr() + n + self.PF_LOOKAHEAD
+        if lo < base or lo >= end or n < (256 << 10):
+            return None
+        return (lo, min(int(n * self.PF_MULT), end - lo))
+
     def _begin(self):
         self.arena.reset()
         self._unit_idx = 0
@@ -333,7 +351,7 @@ class _Net:
         o.groupnorm(x, h, R, HW, w[path + ".norm1.g"], w[path + ".norm1.b"], eps, True, self.cfg.norm_groups, self._gnws)
         h2 = A.alloc(R * HW, cout)
         o.conv2d(h.view(R, H, W, cin), w[path + ".conv1.w"], h2, bias=w[path + ".conv1.b"],
-                 rowbias=temb_all[:, self._temb_slices[path]], rows_per_rb=HW)
+                 rowbias=temb_all[:, self._temb_slices[path]], rows_per_rb=HW, prefetch=self._pf(w[path + ".conv1.w"]))
         h3 = A.alloc(R * HW, cout)
         o.groupnorm(h2, h3, R, HW, w[path + ".norm2.g"], w[path + ".norm2.b"], eps, True, self.cfg.norm_groups, self._gnws)
         if (path + ".conv_shortcut.w") in w:
@@ -341,7 +359,8 @@ class _Net:
             o.gemm(x, w[path + ".conv_shortcut.w"], sc, bias=w[path + ".conv_shortcut.b"])
         else:
             sc = x
-        o.conv2d(h3.view(R, H, W, cout), w[path + ".conv2.w"], out, bias=w[path + ".conv2.b"], res=sc)
+        o.conv2d(h3.view(R, H, W, cout), w[path + ".conv2.w"], out, bias=w[path + ".conv2.b"], res=sc,
+                 prefetch=self._pf(w[path + ".conv2.w"]))
         A.release(m)
         return out
 
@@ -356,17 +375,18 @@ class _Net:
         # -- self-attention (AttnProcessor2_0, attention_processor.py:370-402)
         o.layernorm(h, n, w[p + ".norm1.g"], w[p + ".norm1.b"], 1e-5)
         qk = A.alloc(M, 2 * C)
-        o.gemm(n, w[p + ".attn1.qk.w"], qk)
+        o.gemm(n, w[p + ".attn1.qk.w"], qk, prefetch=self._pf(w[p + ".attn1.qk.w"]))
         vt = A.alloc(C, M)
-        o.gemm(w[p + ".attn1.v.w"], n, vt)                       # V^T = Wv . X^T
+        o.gemm(w[p + ".attn1.v.w"], n, vt, prefetch=self._pf(w[p + ".attn1.v.w"]))     # V^T = Wv . X^T
         a = A.alloc(M, C)
         o.attention(qk[:, :C], a, [(qk[:, C:], T, vt, T, T)], R, heads, T)
-        o.gemm(a, w[p + ".attn1.to_out.0.w"], h, bias=w[p + ".attn1.to_out.0.b"], res=h)
+        o.gemm(a, w[p + ".attn1.to_out.0.w"], h, bias=w[p + ".attn1.to_out.0.b"], res=h,
+               prefetch=self._pf(w[p + ".attn1.to_out.0.w"]))
         # -- decoupled cross-attention (TA_IPAttnProcessor2_0, attention_processor.py:1140-1195)
         if self.cross:
             o.layernorm(h, n, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
             q = qk[:, :C]
-            o.gemm(n, w[p + ".attn2.to_q.w"], q)
+            o.gemm(n, w[p + ".attn2.to_q.w"], q, prefetch=self._pf(w[p + ".attn2.to_q.w"]))
             cfg = self.cfg
             nip, ipad = cfg.num_ip_tokens, (cfg.num_ip_tokens + 7) // 8 * 8
             kv = st["kv"][p]
@@ -380,12 +400,13 @@ class _Net:
                         rows_per_mod=nip, transposed=True, tr_rows=nip, tr_bstride=ipad)
             o.attention(q, a, [(kv["tk"], cfg.text_len, kv["tvt"], kv["tpad"], cfg.text_len), (ipk, nip, ipvt, ipad, nip)],
                         R, heads, T)
-            o.gemm(a, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h)
+            o.gemm(a, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h,
+                   prefetch=self._pf(w[p + ".attn2.to_out.0.w"]))
         # -- GEGLU feed-forward (module/min_sdxl.py:502-528)
         o.layernorm(h, n, w[p + ".norm3.g"], w[p + ".norm3.b"], 1e-5)
         f = A.alloc(M, 4 * C)
-        o.gemm(n, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU)
-        o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h)
+        o.gemm(n, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.w"]))
+        o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]))
         A.release(m)
 
     def _transformer(self, path, x, depth, R, H, W, st, ada, out=None):

@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("epi", C.c_int32), ("act", C.c_int32),
         ("out_scale", C.c_float),
         ("tile", C.c_int32),
+        ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
     ]
 
 
@@ -48,6 +49,7 @@ class ConvDesc(C.Structure):
         ("tile", C.c_int32),
         ("zero_page", C.c_void_p),
         ("x_img_stride", C.c_int64), ("y_img_rows", C.c_int32), ("res_img_rows", C.c_int32), ("pad_mode", C.c_int32),
+        ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
     ]
 
 
