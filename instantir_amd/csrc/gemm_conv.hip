@@ -49,6 +49,13 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     int tiles_m, tiles_n;
     int xm, rm, rn;           // XCD partition: xm x (8/xm) rectangles of rm x rn tiles
     const char* pf; int pf_lines;   // weight prefetch: 128-byte lines to pull towards the Infinity Cache
+    // LayerNorm folding (iir_gemm_desc.ln_*): the A operand (axis 0) or the W operand (axis 1) holds the RAW rows x;
+    // the other operand is gamma-scaled, and the epilogue applies rstd * (acc - mean * s) using per-row statistics
+    // that the kernel which produced x left as partial sums.
+    float* stat_out;                 // [2*tiles_n][M][2] partial (sum, sum of squares) of the rows this launch stores
+    const float* ln_part; int ln_P, ln_axis, ln_rows; float ln_eps, ln_dim;
+    const float* ln_s;               // [N] (axis 0) / [M] (axis 1)
+    const f16* rbias;                // [M] per-row bias (axis 1)
 };
 
 constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
@@ -165,6 +172,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
     // ---- main loop: ST-deep LDS ring, tiles kt+1 .. kt+ST-2 stay in flight across the barrier ---------
     // (one barrier per K tile; the buffer refilled after the barrier is the one every wave finished
     //  reading before it arrived there)
+    // ---- folded LayerNorm, part 1: gather the producer's partial row sums for this tile's rows (axis 0) or
+    // columns (axis 1).  Issued BEFORE the first LDS-DMA tiles so their latency overlaps the pipeline fill; the
+    // per-thread sums go to a small LDS table that the epilogue (many barriers later) finishes into mean / rstd.
+    if (g.ln_part) {
+        const int cnt = g.ln_axis == 0 ? BM : BN, parts = 256 / cnt, base = g.ln_axis == 0 ? m0 : n0;
+        const int part = tid / cnt, r = tid - part * cnt;
+        if (part < parts) {
+            int row = base + r;
+            if (row >= g.ln_rows) row = g.ln_rows - 1;
+            const float* src = g.ln_part + (long)row * 2;
+            const long pstride = (long)g.ln_rows * 2;
+            float su = 0.f, sq = 0.f;
+            int p = part;
+            for (; p + 7 * parts < g.ln_P; p += 8 * parts) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const float2*)(src + (long)(p + u * parts) * pstride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { su += v[u].x; sq += v[u].y; }
+            }
+            for (; p < g.ln_P; p += parts) { const float2 v = *(const float2*)(src + (long)p * pstride); su += v.x; sq += v.y; }
+            float* la = (float*)(smem + ST * (BM + BN) * BK * (int)sizeof(f16) + 1024);
+            la[(part * cnt + r) * 2] = su;
+            la[(part * cnt + r) * 2 + 1] = sq;
+        }
+    }
+
     const int nk = g.K / BK;
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
@@ -209,11 +243,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
         }
     }
 
+    float* lnacc = (float*)(smem + ST * (BM + BN) * BK * (int)sizeof(f16) + 1024);   // [parts][cnt][2], filled in the prologue
+    if (g.ln_part) __syncthreads();   // orders the prologue's table writes before the reads below for any K-loop length
+    const int ln_cnt = g.ln_axis == 0 ? BM : BN, ln_parts = 256 / ln_cnt;
+
     // ---- epilogue: lane holds row m = ..+frow, 4 consecutive columns n = ..+4*fq+{0..3} ---------
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * WM + i * 16 + frow;
+        float st1 = 0.f, st2 = 0.f;                        // row statistics of what this lane stores (stat_out)
+        const int lr = wm * WM + i * 16 + frow;            // row inside the tile
         if (m >= g.M) continue;
+        float ln_mean = 0.f, ln_rstd = 1.f;                // folded LayerNorm, part 2 (axis 0): finish this row's statistics
+        if (g.ln_part && g.ln_axis == 0) {
+            float su = 0.f, sq = 0.f;
+            for (int q = 0; q < ln_parts; ++q) { su += lnacc[(q * ln_cnt + lr) * 2]; sq += lnacc[(q * ln_cnt + lr) * 2 + 1]; }
+            ln_mean = su / g.ln_dim;
+            ln_rstd = rsqrtf(fmaxf(sq / g.ln_dim - ln_mean * ln_mean, 0.f) + g.ln_eps);
+        }
         const f16* rb = g.rowbias ? g.rowbias + (long)(m / g.rows_per_rb) * g.ldrb : nullptr;
         long mc = m, mr = m;                       // row of this output in C and in res
         if (CONV && (g.y_img_rows | g.res_img_rows)) {
@@ -227,6 +274,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 const int n = n0 + wn * WN + j * 16 + fq * 4;
                 if (n >= g.N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (g.ln_part) {
+                    if (g.ln_axis == 0) {
+                        const f32x4 s4 = *(const f32x4*)(g.ln_s + n);
+                        for (int t = 0; t < 4; ++t) v[t] = ln_rstd * (v[t] - ln_mean * s4[t]);
+                    } else {
+                        const int lc = wn * WN + j * 16 + fq * 4;
+                        const float sm = g.ln_s[m];
+                        for (int t = 0; t < 4; ++t) {
+                            float su = 0.f, sq = 0.f;
+                            for (int q = 0; q < ln_parts; ++q) { su += lnacc[(q * ln_cnt + lc + t) * 2]; sq += lnacc[(q * ln_cnt + lc + t) * 2 + 1]; }
+                            const float mean = su / g.ln_dim;
+                            v[t] = rsqrtf(fmaxf(sq / g.ln_dim - mean * mean, 0.f) + g.ln_eps) * (v[t] - mean * sm);
+                        }
+                        if (g.rbias) { const float rbv = (float)g.rbias[m]; for (int t = 0; t < 4; ++t) v[t] += rbv; }
+                    }
+                }
                 if (g.bias) { f16x4 b = *(const f16x4*)(g.bias + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (rb) { f16x4 b = *(const f16x4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
@@ -235,6 +298,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 f16x4 o;
                 for (int t = 0; t < 4; ++t) o[t] = (f16)(v[t] * g.out_scale);
                 *(f16x4*)(g.C + mc * g.ldc + n) = o;
+                if (g.stat_out) for (int t = 0; t < 4; ++t) { const float f = (float)o[t]; st1 += f; st2 += f * f; }
+            }
+            if (g.stat_out) {      // combine the 4 lanes (fq = 0..3) that hold this row, one float2 store per row
+                st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
+                st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
+                if (fq == 0) *(float2*)(g.stat_out + ((long)(tn * 2 + wn) * g.M + m) * 2) = make_float2(st1, st2);
             }
         } else if constexpr (NI % 2 == 0) {
             // paired columns: in every 32-column group of the (row-permuted) weight the first 16 are
@@ -246,6 +315,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 const int no = (n0 + wn * WN + j * 16) / 2 + fq * 4;    // output column
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 float b[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                if (g.ln_part) {
+                    const float mean = ln_mean, rstd = ln_rstd;
+                    const f32x4 sa = *(const f32x4*)(g.ln_s + n), sb = *(const f32x4*)(g.ln_s + n + 16);
+                    for (int t = 0; t < 4; ++t) { a[t] = rstd * (a[t] - mean * sa[t]); b[t] = rstd * (b[t] - mean * sb[t]); }
+                }
                 if (g.bias) {
                     f16x4 ba = *(const f16x4*)(g.bias + n), bb = *(const f16x4*)(g.bias + n + 16);
                     for (int t = 0; t < 4; ++t) { a[t] += (float)ba[t]; b[t] += (float)bb[t]; }
@@ -269,7 +343,7 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = ST * (BM + BN) * BK * sizeof(f16) + 1024;   // + prefetch scratch
+    const size_t lds = ST * (BM + BN) * BK * sizeof(f16) + 1024 + 2048;   // + prefetch scratch + LN-fold partial table (2 blocks of the 128x160 tile must still fit 160 KiB)
     // pick the XCD partition with the least per-L2 operand rows: (tiles_m/xm)*BM + (tiles_n/xn)*BN
     long best = -1;
     static const int force_xm = getenv("IIR_XM") ? atoi(getenv("IIR_XM")) : 0;   // tuning knob: 1,2,4,8 forces the split
@@ -333,6 +407,8 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int iir_gemm_tile_bn(int32_t tile) { tile %= 10; return (tile >= 1 && tile <= 5) ? kTiles[tile].bn : -1; }
+
 extern "C" int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t paired) { return pick_tile(M, N, paired != 0); }
 
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
@@ -351,6 +427,16 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     g.res = (const f16*)d->res; g.ldr = d->ldr; g.epi = d->epi; g.act = d->act;
     g.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     g.pf = (const char*)d->prefetch; g.pf_lines = d->prefetch ? (int)(d->prefetch_bytes / 128) : 0;
+    g.stat_out = (float*)d->stat_out;
+    if (d->ln_part) {
+        if (d->ln_P <= 0 || !d->ln_s || (d->ln_axis != 0 && d->ln_axis != 1)) return IIR_EINVAL;
+        if (d->ln_axis == 1 && d->epi != IIR_EPI_PLAIN) return IIR_EINVAL;
+        if (d->epi == IIR_EPI_SFT) return IIR_EINVAL;
+        g.ln_part = (const float*)d->ln_part; g.ln_P = d->ln_P; g.ln_axis = d->ln_axis; g.ln_eps = d->ln_eps;
+        g.ln_dim = (float)d->K; g.ln_rows = d->ln_axis == 0 ? d->M : d->N;
+        g.ln_s = (const float*)d->ln_s; g.rbias = (const f16*)d->rbias;
+    }
+    if (d->stat_out && d->epi != IIR_EPI_PLAIN) return IIR_EINVAL;
     return dispatch(g, false, d->tile, (hipStream_t)stream);
 }
 

@@ -31,6 +31,8 @@ class GemmDesc(C.Structure):
         ("out_scale", C.c_float),
         ("tile", C.c_int32),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
+        ("stat_out", C.c_void_p), ("ln_part", C.c_void_p), ("ln_P", C.c_int32), ("ln_axis", C.c_int32),
+        ("ln_eps", C.c_float), ("ln_s", C.c_void_p), ("rbias", C.c_void_p),
     ]
 
 
@@ -77,6 +79,7 @@ _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "iir_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "iir_gemm_pick_tile": (C.c_int, [_I32, _I32, _I32]),
+    "iir_gemm_tile_bn": (C.c_int, [_I32]),
     "iir_conv2d_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "iir_attention_d64_f16": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "iir_groupnorm_nhwc_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _P]),
