@@ -31,6 +31,7 @@ extern "C" {
 #define IIR_ACT_NONE 0
 #define IIR_ACT_SILU 1
 #define IIR_ACT_GELU 2 /* erf form */
+#define IIR_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x), CLIP-L text encoder */
 
 /* Pair permutation expected by GEGLU / SFT epilogues: for an op with `n_out` outputs whose
  * "value" rows are V[0..n_out) and partner rows are G[0..n_out), the weight (and bias) handed to
@@ -110,6 +111,7 @@ typedef struct iir_attn_desc {
     int32_t batch, heads, Tq, nseg;                 /* nseg 1 or 2                                   */
     float scale;                                    /* 1/sqrt(64) for SDPA                           */
     iir_attn_kv kv[2];
+    int32_t causal;                                 /* != 0: key j is visible to query i only if j <= i */
 } iir_attn_desc;
 
 /* Replaces F.scaled_dot_product_attention at module/ip_adapter/attention_processor.py:394 (nseg=1)

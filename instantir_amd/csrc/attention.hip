@@ -27,6 +27,7 @@ struct AGeo {
     int Tq, nseg;
     int qtiles, npairs;   // query tiles per (batch, head); number of (batch, head) pairs; heads below
     int heads;
+    int causal;            // mask keys with index > query index (CLIP text encoders)
     float c;   // softmax scale * log2(e)
     Seg seg[2];
 };
@@ -125,6 +126,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
                     kf = *(const f16x8*)(krow + (((2 * ks + hh) ^ sw) * 16));
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
                 }
+            }
+            // ---- causal mask (CLIP text): key index > query index
+            if (g.causal && (t + 1) * KT > q0) {
+                const int qq = q0 + qi;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (key > qq) sacc[kb][r] = -INFINITY;
+                    }
             }
             // ---- tail mask (last tile only; wave-uniform branch)
             if ((t + 1) * KT > s.Tkv) {
@@ -233,6 +245,7 @@ extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
     g.qtiles = (a->Tq + 127) / 128;
     g.npairs = a->heads * a->batch;
     g.heads = a->heads;
+    g.causal = a->causal;
     const dim3 grid(g.npairs * g.qtiles);
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     return iir_launch_status();

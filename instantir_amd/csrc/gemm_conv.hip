@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 if (rb) { f16x4 b = *(const f16x4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
                 else if (g.act == IIR_ACT_GELU) for (int t = 0; t < 4; ++t) v[t] = gelu_erf_f(v[t]);
+                else if (g.act == IIR_ACT_QUICKGELU) for (int t = 0; t < 4; ++t) v[t] = v[t] / (1.0f + __expf(-1.702f * v[t]));
                 if (g.res) { f16x4 r = *(const f16x4*)(g.res + mr * g.ldr + n); for (int t = 0; t < 4; ++t) v[t] += (float)r[t]; }
                 f16x4 o;
                 for (int t = 0; t < 4; ++t) o[t] = (f16)(v[t] * g.out_scale);

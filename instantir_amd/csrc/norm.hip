@@ -17,11 +17,11 @@ constexpr int GN_MAXC = 2560;
 // grid (nslab, R); each thread owns fixed 8-channel chunks so channel sums live in registers.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* X, long ldx, int HW, int C, int G, int pix_per_slab,
                                                        float* part /*[R][nslab][G][2]*/) {
-    __shared__ float csum[GN_MAXC], csq[GN_MAXC];
+    // per-(pixel row, channel) partials, summed afterwards in a FIXED order: bitwise reproducible statistics
+    __shared__ float csum[2048], csq[2048];                 // prows * C <= 256 * 8 whenever nchunk <= 256
+    __shared__ float chs[GN_MAXC], chq[GN_MAXC];
     const int r = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
     const int nchunk = C >> 3;
-    for (int c = threadIdx.x; c < C; c += 256) { csum[c] = 0.f; csq[c] = 0.f; }
-    __syncthreads();
     const int p0 = slab * pix_per_slab;
     const int p1 = min(HW, p0 + pix_per_slab);
     const f16* base = X + (long)r * HW * ldx;
@@ -29,8 +29,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* X, long ldx, i
     const int lanes_c = nchunk < 256 ? nchunk : 256;
     const int prows = 256 / lanes_c;
     const int tc = threadIdx.x % lanes_c, tp = threadIdx.x / lanes_c;
-    if (tp < prows) {
-        for (int ch = tc; ch < nchunk; ch += lanes_c) {
+    for (int c0 = 0; c0 < nchunk; c0 += lanes_c) {            // one pass unless C > 2048
+        const int ch = c0 + tc;
+        if (tp < prows && ch < nchunk) {
             float s[8], q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
@@ -40,14 +41,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* X, long ldx, i
                 for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { atomicAdd(&csum[ch * 8 + j], s[j]); atomicAdd(&csq[ch * 8 + j], q[j]); }
+            for (int j = 0; j < 8; ++j) { csum[(tp * lanes_c + tc) * 8 + j] = s[j]; csq[(tp * lanes_c + tc) * 8 + j] = q[j]; }
         }
+        __syncthreads();
+        for (int c = threadIdx.x; c < lanes_c * 8 && c0 * 8 + c < C; c += 256) {
+            float s = 0.f, q = 0.f;
+            for (int t = 0; t < prows; ++t) { s += csum[t * lanes_c * 8 + c]; q += csq[t * lanes_c * 8 + c]; }
+            chs[c0 * 8 + c] = s; chq[c0 * 8 + c] = q;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int cpg = C / G;
     for (int gi = threadIdx.x; gi < G; gi += 256) {
         float s = 0.f, q = 0.f;
-        for (int c = gi * cpg; c < (gi + 1) * cpg; ++c) { s += csum[c]; q += csq[c]; }
+        for (int c = gi * cpg; c < (gi + 1) * cpg; ++c) { s += chs[c]; q += chq[c]; }
         float* o = part + (((long)r * nslab + slab) * G + gi) * 2;
         o[0] = s; o[1] = q;
     }

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libinstantir_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "instantir_hip.h")
 
 EPI_PLAIN, EPI_GEGLU, EPI_SFT = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3
 
 
 class GemmDesc(C.Structure):
@@ -70,6 +70,7 @@ class AttnDesc(C.Structure):
         ("batch", C.c_int32), ("heads", C.c_int32), ("Tq", C.c_int32), ("nseg", C.c_int32),
         ("scale", C.c_float),
         ("kv", AttnKV * 2),
+        ("causal", C.c_int32),
     ]
 
 

@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import ACT_GELU, ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_SFT  # noqa: F401
+from .lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_SFT  # noqa: F401
 
 
 def _stream():
@@ -167,7 +167,7 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     return out
 
 
-def attention(q, o, kv, batch, heads, Tq, scale=0.125):
+def attention(q, o, kv, batch, heads, Tq, scale=0.125, causal=False):
     """q, o: 2-D views (batch*Tq, heads*64).  kv: list of 1-2 tuples (k2d, k_batch_rows, vt2d, vt_batch_stride, Tkv):
     k2d (batch*k_batch_rows, heads*64) view, vt2d (heads*64, cols) view with batch b starting at column b*vt_batch_stride."""
     _chk2d(q, "q"); _chk2d(o, "o")
@@ -175,6 +175,7 @@ def attention(q, o, kv, batch, heads, Tq, scale=0.125):
     d.Q, d.ldq, d.q_batch_stride = q.data_ptr(), q.stride(0), Tq * q.stride(0)
     d.O, d.ldo, d.o_batch_stride = o.data_ptr(), o.stride(0), Tq * o.stride(0)
     d.batch, d.heads, d.Tq, d.nseg, d.scale = batch, heads, Tq, len(kv), scale
+    d.causal = int(bool(causal))
     for i, (k, k_rows, vt, vbs, tkv) in enumerate(kv):
         _chk2d(k, "k"); _chk2d(vt, "vt")
         d.kv[i].K, d.kv[i].ldk, d.kv[i].k_batch_stride = k.data_ptr(), k.stride(0), k_rows * k.stride(0)

@@ -55,7 +55,8 @@ class InstantIRPipeline:
     vae_scale_factor = 8
 
     def __init__(self, cfg: UNetConfig, unet_state_dict: Dict[str, torch.Tensor], aggregator_state_dict=None,
-                 scheduler=None, vae=None, device="cuda:0"):
+                 scheduler=None, vae=None, device="cuda:0", image_encoder=None, text_encoder=None, text_encoder_2=None,
+                 tokenizer=None, tokenizer_2=None):
         """unet_state_dict: diffusers SDXL names + TA-IP processor + Resampler weights (what
         `load_adapter_to_pipe` leaves in `pipe.unet`, module/ip_adapter/utils.py:136-161)."""
         self.cfg = cfg
@@ -67,6 +68,9 @@ class InstantIRPipeline:
         self.scheduler = scheduler if scheduler is not None else DDPMScheduler()
         self.aggregator = _AggregatorHandle(self)
         self.vae = vae
+        self.image_encoder = image_encoder          # encoders.HipDinov2 (module/ip_adapter/utils.py:106-118)
+        self.text_encoder, self.text_encoder_2 = text_encoder, text_encoder_2     # encoders.HipCLIPText
+        self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2               # callables: list[str] -> (B,77) int64 ids
         self._unet = self._unet_prev = self._agg = None
         self._graphs = {}
         self.use_graphs = True
@@ -135,13 +139,14 @@ class InstantIRPipeline:
                              " only forward one of the two.")
         if prompt is None and prompt_embeds is None:
             raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
-        if prompt is not None:
-            raise NotImplementedError("text encoders are outside this build's hot path: pass `prompt_embeds` / "
-                                      "`pooled_prompt_embeds` (SURVEY.md section 8a row P3)")
+        if prompt is not None and (self.text_encoder is None or self.text_encoder_2 is None or self.tokenizer is None):
+            raise NotImplementedError("`prompt` strings need text encoders + tokenizers attached to the pipeline "
+                                      "(tokenizer vocabularies are not available offline): pass `prompt_embeds` / "
+                                      "`pooled_prompt_embeds`, or `prompt_ids` / `prompt_ids_2`")
         if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
             raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but"
                              f" got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` {negative_prompt_embeds.shape}.")
-        if prompt_embeds is not None and pooled_prompt_embeds is None:
+        if prompt is None and prompt_embeds is not None and pooled_prompt_embeds is None:
             raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed. Make sure to "
                              "generate `pooled_prompt_embeds` from the same text encoder that was used to generate `prompt_embeds`.")
         if negative_prompt_embeds is not None and negative_pooled_prompt_embeds is None:
@@ -162,6 +167,52 @@ class InstantIRPipeline:
             if ip_adapter_image_embeds[0].ndim not in [3, 4]:
                 raise ValueError("`ip_adapter_image_embeds` has to be a list of 3D or 4D tensors but is "
                                  f"{ip_adapter_image_embeds[0].ndim}D")
+
+    def encode_prompt(self, prompt=None, prompt_2=None, negative_prompt=None, negative_prompt_2=None, prompt_ids=None,
+                      prompt_ids_2=None, negative_prompt_ids=None, negative_prompt_ids_2=None, do_cfg=True):
+        """`encode_prompt` (pipelines/sdxl_instantir.py:400-632) on the HIP text encoders: both CLIP encoders'
+        hidden_states[-2] concatenated (B,77,2048) + the second encoder's projected EOS feature (B,1280).  Strings
+        go through the attached tokenizers (77 tokens, padded / truncated); ids may be passed directly.  With no
+        negative prompt the negative embeddings are zeros (`force_zeros_for_empty_prompt`, :567-571)."""
+        from .encoders import encode_prompt_ids
+
+        def ids_of(texts, tok):
+            texts = [texts] if isinstance(texts, str) else list(texts)
+            return tok(texts)
+
+        if prompt_ids is None:
+            prompt_ids = ids_of(prompt, self.tokenizer)
+            prompt_ids_2 = ids_of(prompt_2 if prompt_2 is not None else prompt, self.tokenizer_2 or self.tokenizer)
+        if prompt_ids_2 is None:
+            prompt_ids_2 = prompt_ids
+        pe, pooled = encode_prompt_ids(self.text_encoder, self.text_encoder_2, prompt_ids, prompt_ids_2)
+        npe = npooled = None
+        if do_cfg:
+            if negative_prompt_ids is None and negative_prompt is not None:
+                negative_prompt_ids = ids_of(negative_prompt, self.tokenizer)
+                negative_prompt_ids_2 = ids_of(negative_prompt_2 if negative_prompt_2 is not None else negative_prompt,
+                                               self.tokenizer_2 or self.tokenizer)
+            if negative_prompt_ids is None:
+                npe, npooled = torch.zeros_like(pe), torch.zeros_like(pooled)
+            else:
+                npe, npooled = encode_prompt_ids(self.text_encoder, self.text_encoder_2, negative_prompt_ids,
+                                                 negative_prompt_ids_2 if negative_prompt_ids_2 is not None else negative_prompt_ids)
+        return pe, npe, pooled, npooled
+
+    def encode_image(self, image):
+        """`encode_image`, DINO branch (pipelines/sdxl_instantir.py:660-667): (features, zero-image features).
+        `image`: PIL image(s) (pre-processed like AutoImageProcessor of facebook/dinov2-*) or a normalised tensor."""
+        from .encoders import dinov2_preprocess
+        if self.image_encoder is None:
+            raise NotImplementedError("pass `ip_adapter_image_embeds` or attach an image encoder (encoders.HipDinov2)")
+        px = image if torch.is_tensor(image) else dinov2_preprocess(image)
+        return self.image_encoder.encode_image_pair(px)
+
+    def prepare_ip_adapter_image_embeds(self, ip_adapter_image, do_cfg):
+        """:672-707 for one IP adapter: [(2, B, S, E)] = cat([zero-image features, image features]) under CFG."""
+        f, z = self.encode_image(ip_adapter_image)
+        f, z = f.unsqueeze(0), z.unsqueeze(0)
+        return [torch.cat([z, f]) if do_cfg else f]
 
     @staticmethod
     def _prepare_image(image):
@@ -205,7 +256,12 @@ class InstantIRPipeline:
                                       "(SURVEY.md Appendix C Q5)")
         if guidance_rescale and guidance_rescale > 0.0:
             raise NotImplementedError("guidance_rescale > 0 is not on the benchmarked path (default 0.0)")
-        self.check_inputs(prompt, prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds,
+        if prompt is None and prompt_embeds is None and kwargs.get("prompt_ids") is not None and self.text_encoder is not None:
+            prompt_embeds_chk = kwargs["prompt_ids"]          # ids stand in for the prompt in the exclusivity checks
+        else:
+            prompt_embeds_chk = prompt_embeds
+        self.check_inputs(prompt, prompt_embeds_chk, negative_prompt_embeds,
+                          pooled_prompt_embeds if prompt_embeds_chk is prompt_embeds else torch.zeros(1), negative_pooled_prompt_embeds,
                           ip_adapter_image, ip_adapter_image_embeds, control_guidance_start, control_guidance_end,
                           callback_on_step_end_tensor_inputs)
         self._guidance_scale = guidance_scale
@@ -213,6 +269,12 @@ class InstantIRPipeline:
         do_cfg = self.do_classifier_free_guidance
         self._build()
 
+        if prompt_embeds is None:                                                   # :1325-1348
+            prompt_embeds, ne, pooled_prompt_embeds, npool = self.encode_prompt(
+                prompt, prompt_2, negative_prompt, negative_prompt_2, kwargs.get("prompt_ids"), kwargs.get("prompt_ids_2"),
+                kwargs.get("negative_prompt_ids"), kwargs.get("negative_prompt_ids_2"), do_cfg)
+            if negative_prompt_embeds is None:
+                negative_prompt_embeds, negative_pooled_prompt_embeds = ne, npool
         B = prompt_embeds.shape[0] * num_images_per_prompt
         n_img = 1 if hasattr(image, "size") and not torch.is_tensor(image) and not isinstance(image, (list, tuple)) else len(image)
         assert B == n_img or n_img == 1                                           # :1316-1319
@@ -246,8 +308,10 @@ class InstantIRPipeline:
             raise ValueError("Model expects an added time embedding vector of length "
                              f"{cfg.add_embed_in}, but a vector of {cfg.addition_time_embed_dim * len(ids) + cfg.pooled_dim} was created.")
         time_ids = torch.tensor([ids], dtype=torch.float32).repeat(R, 1)
-        if ip_adapter_image_embeds is None:
-            raise NotImplementedError("pass `ip_adapter_image_embeds` (DINOv2 features); the image encoder is outside this build")
+        if ip_adapter_image_embeds is None:                                         # :1350-1357
+            if ip_adapter_image is None:
+                raise ValueError("InstantIR conditions on the LQ image: pass `ip_adapter_image` or `ip_adapter_image_embeds`")
+            ip_adapter_image_embeds = self.prepare_ip_adapter_image_embeds(ip_adapter_image, do_cfg)
         img = ip_adapter_image_embeds[0]
         if do_cfg:                                                                  # :709-722
             neg, pos = img.chunk(2)
