@@ -61,18 +61,35 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* X, long ldx, i
 }
 
 // ---- GroupNorm pass 2: reduce the slab partials to mean / rstd per (image, group) ------------------
-__global__ void gn_finalize_kernel(const float* part, int nslab, int G, float n_per_group, float eps, float* stat /*[R][G][2]*/) {
-    const int r = blockIdx.x, gi = threadIdx.x;
-    if (gi >= G) return;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int nslab, int G, float n_per_group, float eps,
+                                                          float* stat /*[R][G][2]*/) {
+    // 256 threads per image: thread = (slab lane, group); fixed-order tree over the slab lanes => reproducible
+    __shared__ float ss[256], sq[256];
+    const int r = blockIdx.x;
+    const int lanes = 256 / G;                      // G <= 64 -> >= 4 slab lanes
+    const int gi = threadIdx.x % G, sl = threadIdx.x / G;
     float s = 0.f, q = 0.f;
-    for (int k = 0; k < nslab; ++k) {
-        const float* o = part + (((long)r * nslab + k) * G + gi) * 2;
-        s += o[0]; q += o[1];
+    if (sl < lanes) {
+        const float* base = part + ((long)r * nslab * G + gi) * 2;
+        int k = sl;
+        for (; k + 3 * lanes < nslab; k += 4 * lanes) {
+            const float2 a = *(const float2*)(base + (long)k * G * 2), b = *(const float2*)(base + (long)(k + lanes) * G * 2);
+            const float2 c = *(const float2*)(base + (long)(k + 2 * lanes) * G * 2), d = *(const float2*)(base + (long)(k + 3 * lanes) * G * 2);
+            s += (a.x + b.x) + (c.x + d.x);
+            q += (a.y + b.y) + (c.y + d.y);
+        }
+        for (; k < nslab; k += lanes) { const float2 a = *(const float2*)(base + (long)k * G * 2); s += a.x; q += a.y; }
     }
-    const float mean = s / n_per_group;
-    const float var = fmaxf(q / n_per_group - mean * mean, 0.f);
-    stat[((long)r * G + gi) * 2] = mean;
-    stat[((long)r * G + gi) * 2 + 1] = rsqrtf(var + eps);
+    ss[threadIdx.x] = s; sq[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float ts = 0.f, tq = 0.f;
+        for (int l = 0; l < lanes; ++l) { ts += ss[l * G + threadIdx.x]; tq += sq[l * G + threadIdx.x]; }
+        const float mean = ts / n_per_group;
+        const float var = fmaxf(tq / n_per_group - mean * mean, 0.f);
+        stat[((long)r * G + threadIdx.x) * 2] = mean;
+        stat[((long)r * G + threadIdx.x) * 2 + 1] = rsqrtf(var + eps);
+    }
 }
 
 // ---- GroupNorm pass 3: normalize + affine (+SiLU).  A thread owns fixed 8-channel chunks, so its 16
@@ -261,7 +278,7 @@ extern "C" int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64
     float* stat = part + part_floats;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, R), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, HW, C,
                        groups, pps, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, (const float*)part, nslab, groups,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)part, nslab, groups,
                        (float)HW * (float)(C / groups), eps, stat);
     // apply: ~1024 blocks over the batch
     int nblk = (1024 + R - 1) / R;
