@@ -35,8 +35,8 @@ extern "C" {
 
 /* Pair permutation expected by GEGLU / SFT epilogues: for an op with `n_out` outputs whose
  * "value" rows are V[0..n_out) and partner rows are G[0..n_out), the weight (and bias) handed to
- * the kernel has 2*n_out rows where rows [32*b, 32*b+16) = V[16*b, 16*b+16) and
- * rows [32*b+16, 32*b+32) = G[16*b, 16*b+16).  (Host helper: instantir_amd.packing.pair_rows.) */
+ * the kernel has 2*n_out rows where rows [16*b, 16*b+8) = V[8*b, 8*b+8) and
+ * rows [16*b+8, 16*b+16) = G[8*b, 8*b+8).  (Host helper: instantir_amd.packing.pair_rows.) */
 
 typedef struct iir_gemm_desc {
     const void* A; int64_t lda;    /* [M][K] activations, row stride lda                           */

@@ -67,11 +67,12 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int ST, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
-    constexpr int WM = BM / 2, WN = BN / 2;      // wave tile
+template <int BM, int BN, int ST, bool CONV, int WAVES_M = 2>
+__global__ __launch_bounds__(128 * WAVES_M) void gemm_kernel(const Geo g) {
+    constexpr int NW = WAVES_M * 2, NT = 64 * NW;   // waves laid out WAVES_M x 2 over the tile
+    constexpr int WM = BM / WAVES_M, WN = BN / 2;   // wave tile
     constexpr int MI = WM / 16, NI = WN / 16;    // 16x16 MFMA tiles per wave
-    constexpr int A_INST = BM / 32, B_INST = BN / 32;   // glds instructions per wave per K tile
+    constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;   // glds instructions per wave per K tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16* As = (f16*)smem;                       // [ST][BM][64]
     f16* Bs = As + ST * BM * BK;                // [ST][BN][64]
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
     const f16* a_img[A_INST];
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
-        int m = m0 + (i * 4 + wave) * 8 + srow;
+        int m = m0 + (i * NW + wave) * 8 + srow;
         if (m >= g.M) m = g.M - 1;                    // clamp: tail rows are computed and discarded
         if (!CONV) {
             a_src[i] = g.A + (long)m * g.lda + schunk * 8;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
     const f16* b_src[B_INST];
 #pragma unroll
     for (int i = 0; i < B_INST; ++i) {
-        int n = n0 + (i * 4 + wave) * 8 + srow;
+        int n = n0 + (i * NW + wave) * 8 + srow;
         if (n >= g.N) n = g.N - 1;
         b_src[i] = g.W + (long)n * g.K + schunk * 8;
     }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
         const int k0 = kt * BK;
         if (!CONV) {
 #pragma unroll
-            for (int i = 0; i < A_INST; ++i) glds16(a_src[i] + k0, as + (i * 4 + wave) * 8 * BK);
+            for (int i = 0; i < A_INST; ++i) glds16(a_src[i] + k0, as + (i * NW + wave) * 8 * BK);
         } else {
             const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
             const int ky = tap / g.ks, kx = tap - ky * g.ks;
@@ -146,11 +147,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                     const bool ok = (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.Wd);
                     p = ok ? a_img[i] + ((long)iy * g.Wd + ix) * g.lda + c0 : g.zero + (lane & 7) * 8;
                 }
-                glds16(p, as + (i * 4 + wave) * 8 * BK);
+                glds16(p, as + (i * NW + wave) * 8 * BK);
             }
         }
 #pragma unroll
-        for (int i = 0; i < B_INST; ++i) glds16(b_src[i] + k0, bs + (i * 4 + wave) * 8 * BK);
+        for (int i = 0; i < B_INST; ++i) glds16(b_src[i] + k0, bs + (i * NW + wave) * 8 * BK);
     };
 
     // ---- fragment read offsets (bytes inside a tile image) --------------------------------------
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
     // columns (axis 1).  Issued BEFORE the first LDS-DMA tiles so their latency overlaps the pipeline fill; the
     // per-thread sums go to a small LDS table that the epilogue (many barriers later) finishes into mean / rstd.
     if (g.ln_part) {
-        const int cnt = g.ln_axis == 0 ? BM : BN, parts = 256 / cnt, base = g.ln_axis == 0 ? m0 : n0;
+        const int cnt = g.ln_axis == 0 ? BM : BN, parts = NT / cnt, base = g.ln_axis == 0 ? m0 : n0;
         const int part = tid / cnt, r = tid - part * cnt;
         if (part < parts) {
             int row = base + r;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
         const int per = (g.pf_lines + (int)gridDim.x - 1) / (int)gridDim.x;
         const long l0 = (long)blockIdx.x * per;
         char* scratch = smem + ST * (BM + BN) * BK * (int)sizeof(f16) + wave * 256;
-        for (int i = lane + wave * 64; i < per; i += 256) {
+        for (int i = lane + wave * 64; i < per; i += NT) {
             long l = l0 + i;
             if (l >= g.pf_lines) l = g.pf_lines - 1;
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(g.pf + l * 128), (LDS_AS void*)scratch, 4, 0, 0);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
 
     float* lnacc = (float*)(smem + ST * (BM + BN) * BK * (int)sizeof(f16) + 1024);   // [parts][cnt][2], filled in the prologue
     if (g.ln_part) __syncthreads();   // orders the prologue's table writes before the reads below for any K-loop length
-    const int ln_cnt = g.ln_axis == 0 ? BM : BN, ln_parts = 256 / ln_cnt;
+    const int ln_cnt = g.ln_axis == 0 ? BM : BN, ln_parts = NT / ln_cnt;
 
     // ---- epilogue: lane holds row m = ..+frow, 4 consecutive columns n = ..+4*fq+{0..3} ---------
 #pragma unroll
@@ -306,25 +307,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
                 st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
                 if (fq == 0) *(float2*)(g.stat_out + ((long)(tn * 2 + wn) * g.M + m) * 2) = make_float2(st1, st2);
             }
-        } else if constexpr (NI % 2 == 0) {
-            // paired columns: in every 32-column group of the (row-permuted) weight the first 16 are
-            // the "value" rows and the next 16 their partners (gate for GEGLU; beta for SFT).
+        } else {
+            // paired columns: in every 16-column group of the (row-permuted) weight the first 8 are the "value" rows and
+            // the next 8 their partners (gate for GEGLU; beta for SFT).  A lane holds 4 consecutive columns, so value
+            // lanes (fq = 0,1) fetch their partner from lane + 32 (fq + 2) with one cross-half exchange per register.
 #pragma unroll
-            for (int j = 0; j < NI; j += 2) {
-                const int n = n0 + wn * WN + j * 16 + fq * 4;          // permuted column of the value
-                if (n >= g.N) continue;
-                const int no = (n0 + wn * WN + j * 16) / 2 + fq * 4;    // output column
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * WN + j * 16 + fq * 4;           // permuted column held by this lane
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                float b[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-                if (g.ln_part) {
-                    const float mean = ln_mean, rstd = ln_rstd;
-                    const f32x4 sa = *(const f32x4*)(g.ln_s + n), sb = *(const f32x4*)(g.ln_s + n + 16);
-                    for (int t = 0; t < 4; ++t) { a[t] = rstd * (a[t] - mean * sa[t]); b[t] = rstd * (b[t] - mean * sb[t]); }
+                if (g.ln_part && n < g.N) {
+                    const f32x4 sa = *(const f32x4*)(g.ln_s + n);
+                    for (int t = 0; t < 4; ++t) a[t] = ln_rstd * (a[t] - ln_mean * sa[t]);
                 }
-                if (g.bias) {
-                    f16x4 ba = *(const f16x4*)(g.bias + n), bb = *(const f16x4*)(g.bias + n + 16);
-                    for (int t = 0; t < 4; ++t) { a[t] += (float)ba[t]; b[t] += (float)bb[t]; }
-                }
+                if (g.bias && n < g.N) { f16x4 ba = *(const f16x4*)(g.bias + n); for (int t = 0; t < 4; ++t) a[t] += (float)ba[t]; }
+                float b[4];
+                for (int t = 0; t < 4; ++t) b[t] = __shfl_xor(a[t], 32, 64);     // all lanes take part in the exchange
+                if (fq >= 2 || n >= g.N) continue;
+                const int no = (n0 + wn * WN + j * 16) / 2 + fq * 4;     // output column
                 f16x4 o;
                 if (g.epi == IIR_EPI_GEGLU) {
                     for (int t = 0; t < 4; ++t) o[t] = (f16)(a[t] * gelu_erf_f(b[t]));
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Geo g) {
     if (g.pf_lines > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA must land before the LDS is released
 }
 
-template <int BM, int BN, int ST>
+template <int BM, int BN, int ST, int WAVES_M = 2>
 int launch(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
@@ -355,21 +354,21 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
         const long cost = (long)rm * BM + (long)rn * BN + ((long)rm * rn * 8 - (long)g.tiles_m * g.tiles_n) * 8;
         if (best < 0 || cost < best) { best = cost; g.xm = xm; g.rm = rm; g.rn = rn; }
     }
-    const dim3 grid(8 * g.rm * g.rn), block(256);
+    const dim3 grid(8 * g.rm * g.rn), block(128 * WAVES_M);
     if (conv) {
         static bool attr_c = false;
-        if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, ST, true>), grid, block, lds, stream, g);
+        if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, ST, true, WAVES_M>), grid, block, lds, stream, g);
     } else {
         static bool attr_g = false;
-        if (!attr_g) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, ST, false>), grid, block, lds, stream, g);
+        if (!attr_g) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, false, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, ST, false, WAVES_M>), grid, block, lds, stream, g);
     }
     return iir_launch_status();
 }
 
 struct TileShape { int bm, bn; };
-constexpr TileShape kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
+constexpr TileShape kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}, {256, 128}};
 
 // Tile choice: the per-CU operand fill rate (L2 -> LDS, ~50-70 GB/s) bounds these launches, so pick the
 // shape that minimises the bytes the busiest CU has to pull.  Two workgroups per CU overlap each other's
@@ -378,7 +377,6 @@ int pick_tile(int M, int N, bool paired) {
     long best = -1;
     int pick = 1;
     for (int t = 1; t <= 5; ++t) {
-        if (paired && (kTiles[t].bn / 32) % 2) continue;            // paired epilogues need an even tile count per wave
         const long blocks = (long)((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((N + kTiles[t].bn - 1) / kTiles[t].bn);
         const long cost = ((blocks + 511) / 512) * 2 * (kTiles[t].bm + kTiles[t].bn);
         if (best < 0 || cost < best || (cost == best && kTiles[t].bm * kTiles[t].bn > kTiles[pick].bm * kTiles[pick].bn)) {
@@ -402,13 +400,15 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         case 33: return launch<64, 64, 3>(g, conv, stream);
         case 24: return launch<128, 160, 2>(g, conv, stream);
         case 25: return launch<64, 160, 2>(g, conv, stream);
+        case 26: return launch<256, 128, 2, 4>(g, conv, stream);   // 8 waves, 1 workgroup per CU
+        case 36: return launch<256, 128, 3, 4>(g, conv, stream);
         default: return IIR_EINVAL;
     }
 }
 
 }  // namespace
 
-extern "C" int iir_gemm_tile_bn(int32_t tile) { tile %= 10; return (tile >= 1 && tile <= 5) ? kTiles[tile].bn : -1; }
+extern "C" int iir_gemm_tile_bn(int32_t tile) { tile %= 10; return (tile >= 1 && tile <= 6) ? kTiles[tile].bn : -1; }
 
 extern "C" int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t paired) { return pick_tile(M, N, paired != 0); }
 
@@ -417,8 +417,7 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C) return IIR_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % BK) return IIR_EINVAL;
     if (d->N % 4 || d->lda % 8 || d->ldc % 4) return IIR_EINVAL;
-    if (d->epi != IIR_EPI_PLAIN && (d->N % 32)) return IIR_EINVAL;
-    if (d->epi != IIR_EPI_PLAIN && (d->tile % 10 == 4 || d->tile % 10 == 5)) return IIR_EINVAL;
+    if (d->epi != IIR_EPI_PLAIN && (d->N % 16)) return IIR_EINVAL;
     if (d->epi == IIR_EPI_SFT && !d->res) return IIR_EINVAL;
     if (d->rowbias && d->rows_per_rb <= 0) return IIR_EINVAL;
     Geo g{};
@@ -448,8 +447,7 @@ extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
     if (c->Cin % BK || c->ldx % 8 || c->Cout % 4 || c->ldy % 4) return IIR_EINVAL;
     if (c->stride != 1 && c->stride != 2) return IIR_EINVAL;
     if (c->upsample && c->stride != 1) return IIR_EINVAL;
-    if (c->epi != IIR_EPI_PLAIN && (c->Cout % 32)) return IIR_EINVAL;
-    if (c->epi != IIR_EPI_PLAIN && (c->tile % 10 == 4 || c->tile % 10 == 5)) return IIR_EINVAL;
+    if (c->epi != IIR_EPI_PLAIN && (c->Cout % 16)) return IIR_EINVAL;
     if (c->epi == IIR_EPI_SFT && !c->res) return IIR_EINVAL;
     if (c->rowbias && c->rows_per_rb <= 0) return IIR_EINVAL;
     const int pad = c->pad_mode == 1 ? 0 : c->ksize / 2;   // mode 1: taps reach 1 pixel past the bottom/right edge only

@@ -5,16 +5,16 @@ import torch
 
 
 def pair_rows(value: torch.Tensor, partner: torch.Tensor) -> torch.Tensor:
-    """Interleave two (n, ...) row blocks in groups of 16 rows: [V0..15, G0..15, V16..31, G16..31, ...].
+    """Interleave two (n, ...) row blocks in groups of 8 rows: [V0..7, G0..7, V8..15, G8..15, ...].
 
     This is the layout the GEGLU / SFT epilogues of iir_gemm_f16 / iir_conv2d_nhwc_f16 expect
-    (include/instantir_hip.h "Pair permutation"): the accumulator tile that holds value columns
-    sits next to the tile that holds their partners in the same lane."""
+    (include/instantir_hip.h "Pair permutation"): inside every 16-column MFMA tile the value columns sit in the
+    lower lane half and their partners 32 lanes away, one cross-half exchange apart."""
     n = value.shape[0]
-    if partner.shape != value.shape or n % 16:
-        raise ValueError("pair_rows needs equal shapes with a multiple of 16 rows")
-    v = value.reshape(n // 16, 1, 16, *value.shape[1:])
-    g = partner.reshape(n // 16, 1, 16, *partner.shape[1:])
+    if partner.shape != value.shape or n % 8:
+        raise ValueError("pair_rows needs equal shapes with a multiple of 8 rows")
+    v = value.reshape(n // 8, 1, 8, *value.shape[1:])
+    g = partner.reshape(n // 8, 1, 8, *partner.shape[1:])
     return torch.cat([v, g], dim=1).reshape(2 * n, *value.shape[1:]).contiguous()
 
 

@@ -136,8 +136,8 @@ def test_pair_rows_layout():
     g = v + 100
     p = pair_rows(v, g)
     assert p.shape == (64, 3)
-    assert p[:16, 0].tolist() == list(range(16)) and p[16:32, 0].tolist() == [100 + i for i in range(16)]
-    assert p[32:48, 0].tolist() == list(range(16, 32))
+    assert p[:8, 0].tolist() == list(range(8)) and p[8:16, 0].tolist() == [100 + i for i in range(8)]
+    assert p[16:24, 0].tolist() == list(range(8, 16))
     w = torch.randn(5, 4, 3, 3)
     q = conv_weight_nhwc(w, 64)
     assert q.shape == (5, 3, 3, 64) and torch.equal(q[..., :4], w.permute(0, 2, 3, 1)) and q[..., 4:].abs().max() == 0

@@ -29,7 +29,7 @@ def _close(got, want, rtol=2e-3, atol=2e-3, what=""):
     assert bad == 0, f"{what}: {bad}/{want.numel()} off, max err {err.max().item():.4g} (ref max {want.abs().max().item():.4g})"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 31])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 31, 36])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 132, 64), (2, 320, 320), (1000, 640, 1280)])
 def test_gemm_plain(dev, tile, M, N, K):
     from instantir_amd import ops
