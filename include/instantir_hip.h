@@ -67,8 +67,8 @@ typedef struct iir_gemm_desc {
  * feed-forward module/min_sdxl.py:502-528; proj_in/out :572,575; time_emb_proj :266; embeddings
  * :226-240; AdaLayerNorm linear attention_processor.py:23; Resampler resampler.py:48-49,66-68,95-97. */
 int iir_gemm_f16(const iir_gemm_desc* d, void* stream);
-/* the tile `tile = 0` resolves to for an (M, N) problem (paired != 0 for GEGLU / SFT epilogues) */
-int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t paired);
+/* the tile `tile = 0` resolves to for an (M, N, K) problem (paired != 0 for GEGLU / SFT epilogues) */
+int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired);
 /* output-tile width BN of tile id `tile` (1..5), so callers can size `stat_out` */
 int iir_gemm_tile_bn(int32_t tile);
 

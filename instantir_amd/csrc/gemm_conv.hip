@@ -373,7 +373,9 @@ constexpr TileShape kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 1
 // Tile choice: the per-CU operand fill rate (L2 -> LDS, ~50-70 GB/s) bounds these launches, so pick the
 // shape that minimises the bytes the busiest CU has to pull.  Two workgroups per CU overlap each other's
 // load latency, so capacity is counted in 512 slots: cost = ceil(blocks / 512) * 2 * (BM + BN) [* K * 2 B].
-int pick_tile(int M, int N, bool paired) {
+int pick_tile(int M, int N, bool paired, int K = 0) {
+    // long-K problems that fit one 64x160 workgroup per CU: that tile with a 3-deep ring (see dispatch())
+    if (K >= 2560 && (long)((M + 63) / 64) * ((N + 159) / 160) <= 288) return 5;
     long best = -1;
     int pick = 1;
     for (int t = 1; t <= 5; ++t) {
@@ -389,8 +391,14 @@ int pick_tile(int M, int N, bool paired) {
 
 int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64, 4: 128x160, 5: 64x160}; t + 10*stages selects the ring depth.
-    if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN);
-    if (tile < 10) tile += 10 * IIR_DEFAULT_STAGES;
+    if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
+    if (tile < 10) {
+        // ring depth: with at most one workgroup per CU nothing else hides the tile latency, and a long K loop
+        // amortises the deeper prologue -> 3 stages for the 64x160 tile (measured +17..40 % on K >= 2560, M*N = 2048x1280)
+        const long blocks = (long)((g.M + kTiles[tile].bm - 1) / kTiles[tile].bm) * ((g.N + kTiles[tile].bn - 1) / kTiles[tile].bn);
+        const int stages = (tile == 5 && blocks <= 288 && g.K >= 2560) ? 3 : IIR_DEFAULT_STAGES;
+        tile += 10 * stages;
+    }
     switch (tile) {
         case 21: return launch<128, 128, 2>(g, conv, stream);
         case 31: return launch<128, 128, 3>(g, conv, stream);
@@ -400,6 +408,10 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         case 33: return launch<64, 64, 3>(g, conv, stream);
         case 24: return launch<128, 160, 2>(g, conv, stream);
         case 25: return launch<64, 160, 2>(g, conv, stream);
+        case 35: return launch<64, 160, 3>(g, conv, stream);
+        case 45: return launch<64, 160, 4>(g, conv, stream);
+        case 34: return launch<128, 160, 3>(g, conv, stream);
+        case 42: return launch<128, 64, 4>(g, conv, stream);
         case 26: return launch<256, 128, 2, 4>(g, conv, stream);   // 8 waves, 1 workgroup per CU
         case 36: return launch<256, 128, 3, 4>(g, conv, stream);
         default: return IIR_EINVAL;
@@ -410,7 +422,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
 
 extern "C" int iir_gemm_tile_bn(int32_t tile) { tile %= 10; return (tile >= 1 && tile <= 6) ? kTiles[tile].bn : -1; }
 
-extern "C" int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t paired) { return pick_tile(M, N, paired != 0); }
+extern "C" int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired) { return pick_tile(M, N, paired != 0, K); }
 
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     (void)hipGetLastError();

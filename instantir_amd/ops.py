@@ -64,15 +64,15 @@ PROFILER = None     # set to a LaunchProfiler to time gemm / conv / attention la
 _TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x160", 5: "64x160", 6: "256x128"}
 
 
-def auto_tile(M, N, paired=False):
+def auto_tile(M, N, paired=False, K=0):
     """The tile `tile=0` resolves to (single source of truth: pick_tile() in csrc/gemm_conv.hip)."""
-    return L.load().iir_gemm_pick_tile(M, N, int(paired))
+    return L.load().iir_gemm_pick_tile(M, N, K, int(paired))
 
 
-def stat_partials(M, N, tile=0, paired=False):
+def stat_partials(M, N, tile=0, paired=False, K=0):
     """Number of partial-sum slabs a GEMM with `stat_out` writes: 2 per column tile."""
     if tile == 0:
-        tile = auto_tile(M, N, paired)
+        tile = auto_tile(M, N, paired, K)
     bn = L.load().iir_gemm_tile_bn(tile)
     return 2 * ((N + bn - 1) // bn)
 
@@ -128,7 +128,7 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
         _chk2d(res, "res")
         d.res, d.ldr = res.data_ptr(), res.stride(0)
     if tile == 0:
-        tile = auto_tile(M, N, epi != EPI_PLAIN)
+        tile = auto_tile(M, N, epi != EPI_PLAIN, K)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
@@ -170,7 +170,7 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     pad2 = 1 if pad_mode == 1 else 2 * (ksize // 2)
     Mo = R * ((Hi + pad2 - ksize) // stride + 1) * ((Wi + pad2 - ksize) // stride + 1)
     if tile == 0:
-        tile = auto_tile(Mo, Cout, epi != EPI_PLAIN)
+        tile = auto_tile(Mo, Cout, epi != EPI_PLAIN, ksize * ksize * Cin)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     d.zero_page = zero_page(x.device).data_ptr()
     if prefetch is not None:

@@ -6,7 +6,7 @@ from instantir_amd import ops
 from instantir_amd.packing import conv_weight_nhwc
 
 dev = torch.device("cuda:0")
-TILES = (0, 1, 4, 6, 36)
+TILES = (0, 22, 25, 35)
 
 def timeit(fn, iters=20, warm=3):
     for _ in range(warm): fn()
