@@ -176,6 +176,11 @@ int iir_axpby_f32(const float* x, const float* y, const float* coef, int64_t n, 
  * counterpart: PyTorch streams each layer's weights cold from HBM). */
 int iir_prefetch(const void* p, int64_t bytes, int32_t blocks, void* stream);
 
+/* Seam blending of the tiled VAE decode, in place on tile `b` (fp32 NCHW tiles, `planes` = batch*channels):
+ * blend_v / blend_h of module/diffusers_vae/autoencoder_kl.py:311-321. */
+int iir_blend_tiles_f32(const float* a, float* b, int32_t planes, int32_t Ha, int32_t Wa, int32_t Hb, int32_t Wb,
+                        int32_t extent, int32_t vertical, void* stream);
+
 int iir_transpose_f16(const void* in, int64_t ldi, int32_t rows, int32_t cols, void* out, int64_t ldo, int32_t rows_pad,
                       void* stream);
 int iir_abi_version(void);

@@ -285,3 +285,31 @@ extern "C" int iir_prefetch(const void* p, int64_t bytes, int32_t blocks, void* 
     hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)p, (long)(bytes / 128));
     return iir_launch_status();
 }
+
+namespace {
+// K13: seam blend of tiled VAE decode (module/diffusers_vae/autoencoder_kl.py:311-321), in place on tile b:
+//   vertical:   b[.., y, x] = a[.., Ha - ext + y, x] * (1 - y/ext) + b[.., y, x] * (y/ext),  y < ext
+//   horizontal: b[.., y, x] = a[.., y, Wa - ext + x] * (1 - x/ext) + b[.., y, x] * (x/ext),  x < ext
+__global__ void blend_kernel(const float* a, float* b, int planes, int Ha, int Wa, int Hb, int Wb, int ext, int vertical) {
+    const int rows = vertical ? ext : min(Ha, Hb), cols = vertical ? min(Wa, Wb) : ext;
+    const long n = (long)planes * rows * cols;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % cols), y = (int)((i / cols) % rows), p = (int)(i / ((long)cols * rows));
+    const float w = (float)(vertical ? y : x) / (float)ext;
+    const float av = vertical ? a[((long)p * Ha + (Ha - ext + y)) * Wa + x] : a[((long)p * Ha + y) * Wa + (Wa - ext + x)];
+    float* bp = b + ((long)p * Hb + y) * Wb + x;
+    *bp = av * (1.0f - w) + *bp * w;
+}
+}  // namespace
+
+extern "C" int iir_blend_tiles_f32(const float* a, float* b, int32_t planes, int32_t Ha, int32_t Wa, int32_t Hb, int32_t Wb,
+                                   int32_t extent, int32_t vertical, void* stream) {
+    (void)hipGetLastError();
+    if (!a || !b || planes <= 0 || extent <= 0) return IIR_EINVAL;
+    if (vertical ? (extent > Ha || extent > Hb) : (extent > Wa || extent > Wb)) return IIR_EINVAL;
+    const long n = (long)planes * (vertical ? extent : (Ha < Hb ? Ha : Hb)) * (vertical ? (Wa < Wb ? Wa : Wb) : extent);
+    hipLaunchKernelGGL(blend_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, planes, Ha, Wa, Hb, Wb, extent,
+                       vertical);
+    return iir_launch_status();
+}

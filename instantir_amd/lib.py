@@ -97,6 +97,7 @@ SIGNATURES = {
     "iir_sched_step_f32": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P]),
     "iir_axpby_f32": (C.c_int, [_P, _P, _P, _I64, _P, _P]),
     "iir_prefetch": (C.c_int, [_P, _I64, _I32, _P]),
+    "iir_blend_tiles_f32": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "iir_transpose_f16": (C.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I32, _P]),
     "iir_abi_version": (C.c_int, []),
 }

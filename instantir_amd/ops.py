@@ -329,3 +329,11 @@ def softmax_rows(x):
     _chk2d(x, "x")
     L.check(L.load().iir_softmax_rows_f16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], _stream()), "iir_softmax_rows_f16")
     return x
+
+
+def blend_tiles(a, b, extent, vertical):
+    """In-place seam blend of fp32 NCHW tile `b` with its upper (vertical) or left neighbour `a`."""
+    assert a.dtype == b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    L.check(L.load().iir_blend_tiles_f32(a.data_ptr(), b.data_ptr(), a.shape[0] * a.shape[1], a.shape[2], a.shape[3], b.shape[2],
+                                         b.shape[3], extent, int(vertical), _stream()), "iir_blend_tiles_f32")
+    return b

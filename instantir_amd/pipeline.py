@@ -231,6 +231,50 @@ class InstantIRPipeline:
             raise ValueError(f"image size {tuple(x.shape[2:])} must be a multiple of 8 (infer.py:31-66 resizes to multiples of 64)")
         return x * 2.0 - 1.0
 
+    # ---- single-step previewer restoration (BASELINE configs[4]; spec train_previewer_lora.py:118-145) ------------
+    @torch.no_grad()
+    def restore_single_step(self, image, prompt_embeds, pooled_prompt_embeds, ip_adapter_image_embeds=None,
+                            ip_adapter_image=None, timestep: int = 999, previewer_scheduler=None, generator=None,
+                            init_noise=None, output_type: str = "pil", **kwargs):
+        """LCM one-step restoration with the previewer LoRA, no CFG (guidance 1.0): noise the LQ latent to `timestep`
+        (`prepare_latents` there = scheduler.add_noise), ONE UNet pass with the LoRA enabled, `LCMSingleStepScheduler.step`
+        (schedulers/lcm_single_step_scheduler.py:421-489), VAE decode."""
+        from .engine import CPAD, F16
+        self._build()
+        if self._unet_prev is None:
+            raise RuntimeError("restore_single_step needs the previewer LoRA: call prepare_previewers(...)")
+        sched = previewer_scheduler if previewer_scheduler is not None else LCMSingleStepScheduler.from_config(self.scheduler.config)
+        dev, cfg = self.device, self.cfg
+        image = self._prepare_image(image)
+        if image.shape[1] != 4:
+            if self.vae is None:
+                raise NotImplementedError("pixel-space `image` needs a VAE; pass the LQ latent (B,4,h,w)")
+            image = self.vae.encode_to_latent(image, eps=kwargs.get("vae_noise"))
+        lq = image.to(dev, torch.float32).contiguous()
+        B, _, Hl, Wl = lq.shape
+        if ip_adapter_image_embeds is None:
+            ip_adapter_image_embeds = self.prepare_ip_adapter_image_embeds(ip_adapter_image, False)
+        px = (Hl * self.vae_scale_factor, Wl * self.vae_scale_factor)
+        time_ids = torch.tensor([[px[0], px[1], 0, 0, px[0], px[1]]], dtype=torch.float32).repeat(B, 1)
+        st = self._unet_prev.prepare(prompt_embeds, pooled_prompt_embeds, time_ids, self._unet_prev.resampler(ip_adapter_image_embeds[0]), Hl, Wl)
+        if init_noise is None:
+            gdev = generator.device if generator is not None else dev
+            init_noise = torch.randn(lq.shape, generator=generator, device=gdev, dtype=torch.float32)
+        x = sched.add_noise(lq, init_noise.to(dev, torch.float32), torch.tensor([timestep] * B)).contiguous()
+        lat16 = torch.zeros(B * Hl * Wl, CPAD, dtype=F16, device=dev)
+        ops.pack_latent(x, lat16)
+        t_dev = torch.full((B, 1), float(timestep), dtype=torch.float32, device=dev)
+        eps = self._unet_prev.forward(lat16, t_dev, st)
+        out16 = torch.zeros(B * Hl * Wl, CPAD, dtype=F16, device=dev)
+        out = torch.empty(B, 4, Hl, Wl, dtype=torch.float32, device=dev)
+        coef = torch.tensor(sched.preview_coefficients(timestep), dtype=torch.float32).to(dev)
+        ops.lcm_step(eps, B, 1, coef, x, out16, out)
+        if output_type == "latent":
+            return StableDiffusionXLPipelineOutput(images=out)
+        if self.vae is None:
+            raise NotImplementedError("output_type other than 'latent' needs a VAE attached to the pipeline")
+        return StableDiffusionXLPipelineOutput(images=self.vae.decode_latent(out, output_type))
+
     # ---- the call ---------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, prompt=None, prompt_2=None, image=None, height=None, width=None, num_inference_steps: int = 30,
@@ -394,6 +438,8 @@ class InstantIRPipeline:
             if self.vae is None:
                 raise NotImplementedError("output_type other than 'latent' needs a VAE attached to the pipeline")
             image_out = self.vae.decode_latent(latents_out, output_type)
+        if save_preview_row and self.vae is not None and output_type != "latent":     # :1706-1729 (decoded independently, Q4)
+            preview_row = [self.vae.decode_latent(pl, output_type) for pl in preview_row]
         if not return_dict:
             return (image_out, preview_row) if save_preview_row else (image_out,)
         return StableDiffusionXLPipelineOutput(images=image_out)

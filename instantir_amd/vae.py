@@ -34,6 +34,7 @@ class HipVAE:
         self._sized = {}
         self.has_decoder = "decoder.conv_in.weight" in sd
         self.has_encoder = "encoder.conv_in.weight" in sd
+        self.tile_sample_size = 1024         # AutoencoderKL config.sample_size (autoencoder_kl.py:117-124)
         t = lambda n: sd[n].to(device=self.device, dtype=F16)
         for name in sd:
             if not name.endswith(".weight"):
@@ -166,10 +167,38 @@ class HipVAE:
         o.unpack_latent(img, out)
         return out
 
-    def decode_latent(self, latents: torch.Tensor, output_type: str = "pt"):
+    def decode_tiled(self, z: torch.Tensor, sample_size: int = 1024, overlap: float = 0.25) -> torch.Tensor:
+        """`AutoencoderKL.tiled_decode` (module/diffusers_vae/autoencoder_kl.py:377-423): overlapping latent tiles of
+        sample_size/8 (stride = tile * (1 - overlap)), each decoded on its own, seams blended over sample_size * overlap
+        pixels against the already blended upper / left neighbour, tiles cropped to sample_size * (1 - overlap) and
+        concatenated.  1024-px tiles / 256-px blends / 768-px crops for SDXL."""
+        z = z.to(self.device, torch.float32)
+        tl = sample_size // 8
+        stride = int(tl * (1 - overlap))
+        ext = int(sample_size * overlap)
+        limit = sample_size - ext
+        rows = []
+        for i in range(0, z.shape[2], stride):
+            rows.append([self.decode(z[:, :, i:i + tl, j:j + tl].contiguous()).contiguous() for j in range(0, z.shape[3], stride)])
+        out_rows = []
+        for i, row in enumerate(rows):
+            parts = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    up = rows[i - 1][j]
+                    ops.blend_tiles(up, tile, min(up.shape[2], tile.shape[2], ext), True)
+                if j > 0:
+                    left = row[j - 1]
+                    ops.blend_tiles(left, tile, min(left.shape[3], tile.shape[3], ext), False)
+                parts.append(tile[:, :, :limit, :limit])
+            out_rows.append(torch.cat(parts, dim=3))
+        return torch.cat(out_rows, dim=2)
+
+    def decode_latent(self, latents: torch.Tensor, output_type: str = "pt", tiled: bool = False):
         """pipelines/sdxl_instantir.py:1689-1704: latents / scaling_factor -> decode -> postprocess
         (VaeImageProcessor: (x / 2 + 0.5).clamp(0, 1); 'pt' tensor, 'np' NHWC array, 'pil' images)."""
-        img = self.decode(latents.to(self.device, torch.float32) / self.cfg.scaling_factor)
+        z = latents.to(self.device, torch.float32) / self.cfg.scaling_factor
+        img = self.decode_tiled(z, self.tile_sample_size) if tiled and max(z.shape[2:]) > self.tile_sample_size // 8 else self.decode(z)
         img = (img / 2 + 0.5).clamp(0, 1)
         if output_type == "pt":
             return img

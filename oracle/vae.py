@@ -82,3 +82,35 @@ def encode(P, vc, img, eps):
     mean, logvar = torch.chunk(x, 2, dim=1)
     std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
     return mean + std * eps
+
+
+def decode_tiled(P, vc, z, sample_size=1024, overlap=0.25):
+    """AutoencoderKL.tiled_decode + blend_v / blend_h, module/diffusers_vae/autoencoder_kl.py:311-321,377-423."""
+    tl = sample_size // 8
+    stride, ext = int(tl * (1 - overlap)), int(sample_size * overlap)
+    limit = sample_size - ext
+    rows = [[decode(P, vc, z[:, :, i:i + tl, j:j + tl]) for j in range(0, z.shape[3], stride)] for i in range(0, z.shape[2], stride)]
+
+    def blend_v(a, b, e):
+        e = min(a.shape[2], b.shape[2], e)
+        for y in range(e):
+            b[:, :, y, :] = a[:, :, -e + y, :] * (1 - y / e) + b[:, :, y, :] * (y / e)
+        return b
+
+    def blend_h(a, b, e):
+        e = min(a.shape[3], b.shape[3], e)
+        for x in range(e):
+            b[:, :, :, x] = a[:, :, :, -e + x] * (1 - x / e) + b[:, :, :, x] * (x / e)
+        return b
+
+    out = []
+    for i, row in enumerate(rows):
+        parts = []
+        for j, tile in enumerate(row):
+            if i > 0:
+                tile = blend_v(rows[i - 1][j], tile, ext)
+            if j > 0:
+                tile = blend_h(row[j - 1], tile, ext)
+            parts.append(tile[:, :, :limit, :limit])
+        out.append(torch.cat(parts, dim=3))
+    return torch.cat(out, dim=2)

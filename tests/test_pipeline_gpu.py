@@ -115,3 +115,27 @@ def test_no_cfg_single_image(env):
                init_noise=one["init_noise"]).images.float().cpu()
     p = psnr(got, want)
     assert p >= 40, p
+
+
+def test_single_step_previewer_restoration(env):
+    """BASELINE configs[4] control flow: LQ latent noised to t = 999, one LoRA-UNet pass, LCM one-step x0, no CFG
+    (train_previewer_lora.py:118-145; schedulers/lcm_single_step_scheduler.py:421-489)."""
+    from instantir_amd.schedulers import DDPMScheduler
+    from oracle import nets, sched
+    cfg, sd, sda, lora, inp = env
+    pipe = _pipe(cfg, sd, sda, lora, DDPMScheduler())
+    feats = inp["img"][1:]
+    got = pipe.restore_single_step(inp["lq"], inp["pe"], inp["pooled"], ip_adapter_image_embeds=[feats], init_noise=inp["init_noise"],
+                                   output_type="latent").images.float().cpu()
+    P = {k: v.float() for k, v in sd.items()}
+    L = {k: v.float() for k, v in lora.items()}
+    L["scaling"] = 16.0 / cfg.lora_rank
+    acp = sched.make_alphas_cumprod()
+    B = inp["B"]
+    x = sched.add_noise(acp, inp["lq"], inp["init_noise"], [999] * B)
+    tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]]).repeat(B, 1)
+    ip = nets.image_projection(P, [feats], cfg.resampler, L)[0]
+    eps = nets.unet_forward(P, cfg, x, 999, inp["pe"], inp["pooled"], tid, ip, lora=L)
+    want = sched.lcm_step(acp, eps, 999, x)
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p >= 40, p

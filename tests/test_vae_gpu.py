@@ -128,3 +128,17 @@ def test_pipeline_pixels_in_pixels_out(vae_env, dev):
     mse = ((got - want) ** 2).mean().item()
     p = 10 * math.log10(1.0 / max(mse, 1e-30))
     assert p > 35, p
+
+
+def test_vae_tiled_decode_matches_oracle(vae_env):
+    """Tiled decode with seam blending (BASELINE configs[3] path): 3 x 3 overlapping tiles at the tiny geometry
+    (tile 16 latent px = 128 px, stride 12, blend 32 px, crop 96 px; ragged 8-px last row / column)."""
+    from oracle import vae as OV
+    vc, sd, hv = vae_env
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(1, 4, 32, 32, generator=g)
+    want = OV.decode_tiled({k: v.float() for k, v in sd.items()}, vc, z, sample_size=128)
+    got = hv.decode_tiled(z, sample_size=128).cpu()
+    assert got.shape == want.shape
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p > 40, p
