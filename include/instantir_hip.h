@@ -133,6 +133,19 @@ int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t 
                       const void* beta, float eps, const void* shift, const void* scale, int64_t ldmod,
                       int32_t rows_per_mod, int32_t transposed, int32_t tr_rows, int64_t tr_bstride, void* stream);
 
+/* Every adaLN of one UNet forward in one launch.  The IP-adapter tokens are step invariant, so the raw to_k_ip /
+ * to_v_ip projections are hoisted; what is left per step and per TA-IP block is AdaLayerNorm(raw, temb)
+ * (module/ip_adapter/attention_processor.py:14-26 as called at :1173-1176): LN without affine, then * (1 + scale) + shift.
+ * jobs_dev: DEVICE array of njobs records; all jobs share rows, eps, ldmod (row stride of the shift / scale matrix),
+ * rows_per_mod, tr_rows and tr_bstride (meaning as in iir_layernorm_f16); max_C = largest C in the table. */
+typedef struct iir_adaln_job {
+    const void* X; void* Y; const void* shift; const void* scale;
+    int64_t ldx, ldy;
+    int32_t C, transposed;
+} iir_adaln_job;
+int iir_adaln_batch_f16(const iir_adaln_job* jobs_dev, int32_t njobs, int32_t rows, int32_t max_C, float eps, int64_t ldmod,
+                        int32_t rows_per_mod, int32_t tr_rows, int64_t tr_bstride, void* stream);
+
 /* In-place row softmax (fp32 math) of an fp16 matrix, cols <= 16384: the score matrix of the VAE mid-block
  * attention (1 head of dim 512, T = (H/8)*(W/8) tokens; torch.softmax inside F.scaled_dot_product_attention,
  * module/ip_adapter/attention_processor.py:394 as used by module/unet/unet_2d_ZeroSFT_blocks.py:776-790). */

@@ -373,9 +373,17 @@ constexpr TileShape kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 1
 // Tile choice: the per-CU operand fill rate (L2 -> LDS, ~50-70 GB/s) bounds these launches, so pick the
 // shape that minimises the bytes the busiest CU has to pull.  Two workgroups per CU overlap each other's
 // load latency, so capacity is counted in 512 slots: cost = ceil(blocks / 512) * 2 * (BM + BN) [* K * 2 B].
+// One workgroup per CU leaves nothing else to hide the L2 -> LDS latency: long-K launches of that kind take the 64x160
+// tile with a deeper ring.  Cold-weight sweep (tools/tilebench.py, us): 2048x1280x5120  128x64/2 67.0 | 64x160/3 47.3 | /4 46.1;
+// 2048x1280x1280  128x64/2 21.9 | 64x160/3 16.7 | /4 16.3 -- but inside the loop (weights prefetched by the previous
+// launch, a second stream sharing the CUs) extending the rule to K = 1280 measured 79.4 vs 78.2 ms/step, so it stays
+// at K >= 2560 / 3 stages (IIR_T5_MINK / IIR_T5_STAGES override for experiments).
+int one_per_cu_min_k() { static const int v = [] { const char* e = getenv("IIR_T5_MINK"); return e ? atoi(e) : 2560; }(); return v; }
+int one_per_cu_stages() { static const int v = [] { const char* e = getenv("IIR_T5_STAGES"); return e ? atoi(e) : 3; }(); return v; }
+
 int pick_tile(int M, int N, bool paired, int K = 0) {
-    // long-K problems that fit one 64x160 workgroup per CU: that tile with a 3-deep ring (see dispatch())
-    if (K >= 2560 && (long)((M + 63) / 64) * ((N + 159) / 160) <= 288) return 5;
+    // problems that fit one 64x160 workgroup per CU: that tile with a deep ring (see dispatch())
+    if (K >= one_per_cu_min_k() && (long)((M + 63) / 64) * ((N + 159) / 160) <= 256) return 5;
     long best = -1;
     int pick = 1;
     for (int t = 1; t <= 5; ++t) {
@@ -396,7 +404,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         // ring depth: with at most one workgroup per CU nothing else hides the tile latency, and a long K loop
         // amortises the deeper prologue -> 3 stages for the 64x160 tile (measured +17..40 % on K >= 2560, M*N = 2048x1280)
         const long blocks = (long)((g.M + kTiles[tile].bm - 1) / kTiles[tile].bm) * ((g.N + kTiles[tile].bn - 1) / kTiles[tile].bn);
-        const int stages = (tile == 5 && blocks <= 288 && g.K >= 2560) ? 3 : IIR_DEFAULT_STAGES;
+        const int stages = (tile == 5 && blocks <= 256 && g.K >= one_per_cu_min_k()) ? one_per_cu_stages() : IIR_DEFAULT_STAGES;
         tile += 10 * stages;
     }
     switch (tile) {

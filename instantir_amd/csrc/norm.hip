@@ -137,12 +137,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, long ldx, f
 // y = LN(x) * gamma + beta                      (gamma/beta optional)
 // y = y * (1 + scale[row / rows_per_mod]) + shift[row / rows_per_mod]   (optional adaLN modulation)
 // transposed != 0 writes y^T: Y[c][col_off(row)] with col = (row / tr_rows) * tr_bstride + row % tr_rows.
-__global__ __launch_bounds__(256) void ln_kernel(const f16* X, long ldx, f16* Y, long ldy, int rows, int C, const f16* gamma,
-                                                 const f16* beta, float eps, const f16* shift, const f16* scale, long ldmod,
-                                                 int rows_per_mod, int transposed, int tr_rows, long tr_bstride) {
+__device__ __forceinline__ void ln_row(const f16* X, long ldx, f16* Y, long ldy, int row, int C, const f16* gamma,
+                                       const f16* beta, float eps, const f16* shift, const f16* scale, long ldmod,
+                                       int rows_per_mod, int transposed, int tr_rows, long tr_bstride) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     const int nchunk = C >> 3;
     constexpr int MAXK = GN_MAXC / 8 / 64;   // 5 chunks per lane
     f16x8 v[MAXK];
@@ -196,6 +194,24 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* X, long ldx, f16* Y,
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void ln_kernel(const f16* X, long ldx, f16* Y, long ldy, int rows, int C, const f16* gamma,
+                                                 const f16* beta, float eps, const f16* shift, const f16* scale, long ldmod,
+                                                 int rows_per_mod, int transposed, int tr_rows, long tr_bstride) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    ln_row(X, ldx, Y, ldy, row, C, gamma, beta, eps, shift, scale, ldmod, rows_per_mod, transposed, tr_rows, tr_bstride);
+}
+
+// Every adaLN of one UNet forward in one launch: blockIdx.y walks a device table of iir_adaln_job records.
+__global__ __launch_bounds__(256) void adaln_batch_kernel(const iir_adaln_job* jobs, int rows, float eps, long ldmod,
+                                                          int rows_per_mod, int tr_rows, long tr_bstride) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const iir_adaln_job j = jobs[blockIdx.y];
+    ln_row((const f16*)j.X, j.ldx, (f16*)j.Y, j.ldy, row, j.C, nullptr, nullptr, eps, (const f16*)j.shift, (const f16*)j.scale,
+           ldmod, rows_per_mod, j.transposed, tr_rows, tr_bstride);
 }
 
 // ---- row softmax in place (VAE mid-block attention scores: one head of dim C, T up to 16384) --------
@@ -303,5 +319,15 @@ extern "C" int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ld
     hipLaunchKernelGGL(ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, (f16*)Y,
                        (long)ldy, rows, C, (const f16*)gamma, (const f16*)beta, eps, (const f16*)shift, (const f16*)scale,
                        (long)ldmod, rows_per_mod, transposed, tr_rows, (long)tr_bstride);
+    return iir_launch_status();
+}
+
+extern "C" int iir_adaln_batch_f16(const iir_adaln_job* jobs_dev, int32_t njobs, int32_t rows, int32_t max_C, float eps,
+                                   int64_t ldmod, int32_t rows_per_mod, int32_t tr_rows, int64_t tr_bstride, void* stream) {
+    (void)hipGetLastError();
+    if (!jobs_dev || njobs <= 0 || njobs > 65535 || rows <= 0 || rows_per_mod <= 0) return IIR_EINVAL;
+    if (max_C <= 0 || max_C > GN_MAXC || max_C % 8) return IIR_EINVAL;
+    hipLaunchKernelGGL(adaln_batch_kernel, dim3((rows + 3) / 4, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, rows, eps,
+                       (long)ldmod, rows_per_mod, tr_rows, (long)tr_bstride);
     return iir_launch_status();
 }

@@ -390,14 +390,7 @@ class _Net:
             cfg = self.cfg
             nip, ipad = cfg.num_ip_tokens, (cfg.num_ip_tokens + 7) // 8 * 8
             kv = st["kv"][p]
-            ipk = A.alloc(R * nip, C)
-            ipvt = A.alloc(C, R * ipad)
-            sk, sv = self._ada_slices[p + ".k"], self._ada_slices[p + ".v"]
-            # adaLN: shift first, then scale (attention_processor.py:24)
-            o.layernorm(kv["ipk_raw"], ipk, eps=1e-6, shift=ada[:, sk.start:sk.start + C], scale=ada[:, sk.start + C:sk.stop],
-                        rows_per_mod=nip)
-            o.layernorm(kv["ipv_raw"], ipvt, eps=1e-6, shift=ada[:, sv.start:sv.start + C], scale=ada[:, sv.start + C:sv.stop],
-                        rows_per_mod=nip, transposed=True, tr_rows=nip, tr_bstride=ipad)
+            ipk, ipvt = kv["ipk"], kv["ipvt"]          # adaLN'd for this step by the batched launch in _embeddings
             o.attention(q, a, [(kv["tk"], cfg.text_len, kv["tvt"], kv["tpad"], cfg.text_len), (ipk, nip, ipvt, ipad, nip)],
                         R, heads, T)
             o.gemm(a, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h,
@@ -445,8 +438,12 @@ class _Net:
         o.gemm(act, w["temb_all.w"], temb_all, bias=w["temb_all.b"])
         ada = None
         if "ada_all.w" in w:
-            ada = A.alloc(R, w["ada_all.w"].shape[0])
+            ada = st["ada"]
             o.gemm(act, w["ada_all.w"], ada, bias=w["ada_all.b"])
+            # AdaLayerNorm of every block's hoisted IP K / V in one launch (attention_processor.py:14-26,1173-1176)
+            nip = cfg.num_ip_tokens
+            o.adaln_batch(st["ada_jobs"], st["ada_njobs"], R * nip, max(cfg.block_out_channels), ada.stride(0), nip, nip,
+                          (nip + 7) // 8 * 8)
         return temb_all, ada
 
     def _aug_emb(self, text_embeds, time_ids):
@@ -589,6 +586,7 @@ class HipUNet(_Net):
         ctx2 = ctx.to(dev, F16).reshape(R * L, -1).contiguous()
         ip2 = ip_tokens.to(dev, F16).reshape(R * cfg.num_ip_tokens, -1).contiguous()
         tpad = (L + 7) // 8 * 8
+        nip, ipad = cfg.num_ip_tokens, (cfg.num_ip_tokens + 7) // 8 * 8
         st = {"R": R, "H": H, "W": W, "aug_emb": self._aug_emb(text_embeds, time_ids), "kv": {}}
         blocks = sorted({k[: -len(".attn2.to_k.w")] for k in w if k.endswith(".attn2.to_k.w")})
         for p in blocks:
@@ -604,7 +602,18 @@ class HipUNet(_Net):
             ops.gemm(ip2, w[p + ".attn2.processor.to_k_ip.w"], ipk)
             ipv = torch.empty(R * cfg.num_ip_tokens, C, dtype=F16, device=dev)
             ops.gemm(ip2, w[p + ".attn2.processor.to_v_ip.w"], ipv)
-            st["kv"][p] = {"tk": tk, "tvt": tvt, "tpad": tpad, "ipk_raw": ipk, "ipv_raw": ipv}
+            st["kv"][p] = {"tk": tk, "tvt": tvt, "tpad": tpad, "ipk_raw": ipk, "ipv_raw": ipv,
+                           "ipk": torch.zeros(R * nip, C, dtype=F16, device=dev), "ipvt": torch.zeros(C, R * ipad, dtype=F16, device=dev)}
+        # per-step adaLN of the raw IP K / V: shift first, then scale (attention_processor.py:24); V is emitted transposed
+        st["ada"] = torch.zeros(R, w["ada_all.w"].shape[0], dtype=F16, device=dev)
+        jobs = []
+        for p in blocks:
+            kv, C = st["kv"][p], w[p + ".attn2.to_k.w"].shape[0]
+            sk, sv = self._ada_slices[p + ".k"], self._ada_slices[p + ".v"]
+            ada = st["ada"]
+            jobs.append((kv["ipk_raw"], kv["ipk"], ada[:, sk.start:sk.start + C], ada[:, sk.start + C:sk.stop], False))
+            jobs.append((kv["ipv_raw"], kv["ipvt"], ada[:, sv.start:sv.start + C], ada[:, sv.start + C:sv.stop], True))
+        st["ada_jobs"], st["ada_njobs"] = ops.adaln_job_table(jobs, dev), len(jobs)
         key = (R, H, W)
         if self._sized != key:
             dummy = torch.empty(R * H * W, CPAD, dtype=F16, device="meta")

@@ -63,6 +63,13 @@ class AttnKV(C.Structure):
     ]
 
 
+class AdaLNJob(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("Y", C.c_void_p), ("shift", C.c_void_p), ("scale", C.c_void_p),
+        ("ldx", C.c_int64), ("ldy", C.c_int64), ("C", C.c_int32), ("transposed", C.c_int32),
+    ]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("ldq", C.c_int64), ("q_batch_stride", C.c_int64),
@@ -86,6 +93,7 @@ SIGNATURES = {
     "iir_groupnorm_nhwc_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _P]),
     "iir_groupnorm_workspace_bytes": (C.c_int64, [_I32, _I32]),
     "iir_layernorm_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _F, _P, _P, _I64, _I32, _I32, _I32, _I64, _P]),
+    "iir_adaln_batch_f16": (C.c_int, [_P, _I32, _I32, _I32, _F, _I64, _I32, _I32, _I64, _P]),
     "iir_softmax_rows_f16": (C.c_int, [_P, _I64, _I32, _I32, _P]),
     "iir_sinusoid_f16": (C.c_int, [_P, _I32, _I32, _I32, _P, _I64, _I32, _P]),
     "iir_silu_f16": (C.c_int, [_P, _P, _I64, _P]),

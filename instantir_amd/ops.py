@@ -242,6 +242,23 @@ def layernorm(x, out, gamma=None, beta=None, eps=1e-5, shift=None, scale=None, r
     return out
 
 
+def adaln_job_table(jobs, device):
+    """jobs: list of (x, out, shift, scale, transposed) 2-D fp16 views -> device table of iir_adaln_job records.
+    The caller keeps the views alive; the table holds raw addresses."""
+    arr = (L.AdaLNJob * len(jobs))()
+    for i, (x, out, shift, scale, tr) in enumerate(jobs):
+        _chk2d(x, "x"); _chk2d(out, "out")
+        arr[i] = L.AdaLNJob(x.data_ptr(), out.data_ptr(), shift.data_ptr(), scale.data_ptr(), x.stride(0), out.stride(0),
+                            x.shape[1], int(tr))
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return raw.to(device)
+
+
+def adaln_batch(table, njobs, rows, max_C, ldmod, rows_per_mod, tr_rows, tr_bstride, eps=1e-6):
+    L.check(L.load().iir_adaln_batch_f16(table.data_ptr(), njobs, rows, max_C, eps, ldmod, rows_per_mod, tr_rows, tr_bstride,
+                                         _stream()), "iir_adaln_batch_f16")
+
+
 def sinusoid(vals, out, dim, col_off=0):
     """vals fp32 (rows, n_vals) device tensor; out 2-D fp16 view."""
     rows, n_vals = vals.shape

@@ -26,13 +26,14 @@ def test_descriptor_layouts_match_header():
     import shutil
     import subprocess
     import tempfile
-    sizes = (ctypes.sizeof(lib.GemmDesc), ctypes.sizeof(lib.ConvDesc), ctypes.sizeof(lib.AttnKV), ctypes.sizeof(lib.AttnDesc))
+    sizes = (ctypes.sizeof(lib.GemmDesc), ctypes.sizeof(lib.ConvDesc), ctypes.sizeof(lib.AttnKV), ctypes.sizeof(lib.AttnDesc),
+             ctypes.sizeof(lib.AdaLNJob))
     assert all(s % 8 == 0 for s in sizes) and sizes[2] == 56
     if shutil.which("gcc"):      # ask the C compiler itself
         with tempfile.TemporaryDirectory() as td:
             src = os.path.join(td, "sz.c")
-            open(src, "w").write('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu", sizeof(iir_gemm_desc),'
-                                 'sizeof(iir_conv_desc), sizeof(iir_attn_kv), sizeof(iir_attn_desc));}' % lib.HEADER_PATH)
+            open(src, "w").write('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu", sizeof(iir_gemm_desc),'
+                                 'sizeof(iir_conv_desc), sizeof(iir_attn_kv), sizeof(iir_attn_desc), sizeof(iir_adaln_job));}' % lib.HEADER_PATH)
             subprocess.run(["gcc", src, "-o", os.path.join(td, "sz")], check=True)
             out = subprocess.run([os.path.join(td, "sz")], capture_output=True, text=True, check=True).stdout
         assert tuple(int(x) for x in out.split()) == sizes

@@ -257,6 +257,33 @@ def test_layernorm_variants(dev):
     _close(outT, want.reshape(32, 128).T, what="adaLN^T")
 
 
+def test_adaln_batch_matches_single_launches(dev):
+    """iir_adaln_batch_f16: one launch over a job table == the per-block iir_layernorm_f16 launches, bit for bit."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(41)
+    R, nip, ipad = 2, 16, 16
+    mod = _rand(g, R, 2 * (128 + 256) * 2, scale=0.3).to(dev)
+    jobs, singles, off = [], [], 0
+    for C in (128, 256):
+        for tr in (False, True):
+            x = (_rand(g, R * nip, C) * 1.5 + 0.2).to(dev)
+            out = torch.zeros((C, R * ipad) if tr else (R * nip, C), dtype=torch.half, device=dev)
+            ref = torch.zeros_like(out)
+            sh, sc = mod[:, off:off + C], mod[:, off + C:off + 2 * C]
+            off += 2 * C
+            jobs.append((x, out, sh, sc, tr))
+            ops.layernorm(x, ref, eps=1e-6, shift=sh, scale=sc, rows_per_mod=nip, transposed=tr, tr_rows=nip, tr_bstride=ipad)
+            singles.append(ref)
+    table = ops.adaln_job_table(jobs, dev)
+    ops.adaln_batch(table, len(jobs), R * nip, 256, mod.stride(0), nip, nip, ipad)
+    torch.cuda.synchronize()
+    for (x, out, *_), ref in zip(jobs, singles):
+        assert torch.equal(out, ref)
+    want = F.layer_norm(jobs[0][0].float(), (128,), None, None, 1e-6).reshape(R, nip, 128) * (1 + jobs[0][3].float()[:, None]) \
+        + jobs[0][2].float()[:, None]
+    _close(jobs[0][1], want.reshape(R * nip, 128).cpu(), what="adaLN batch")
+
+
 def test_pointwise(dev):
     from instantir_amd import ops
     g = torch.Generator().manual_seed(8)
