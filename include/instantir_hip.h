@@ -49,17 +49,8 @@ typedef struct iir_gemm_desc {
     int32_t epi, act;
     float out_scale;               /* 0 means 1                                                    */
     int32_t tile;                  /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x160, 5 = 64x160 */
-    const void* prefetch;          /* optional: range the workgroups touch after their K loop so it is   */
-    int64_t prefetch_bytes;        /*   in the Infinity Cache for a LATER launch (next layers' weights)   */
-    /* LayerNorm folding -- LN(x) @ W^T computed as rstd*(x @ (W*gamma)^T - mean*s) + (W beta + b) with NO LayerNorm
-     * launch (nn.LayerNorm call sites module/min_sdxl.py:534-538 feeding the Linear layers :541-560):          */
-    void* stat_out;                /* fp32 [2*ceil(N/BN)][M][2]: per-row partial (sum, sum^2) of the stored C   */
-                                   /*   (BN = tile width, see iir_gemm_tile_bn); PLAIN epilogue only           */
-    const void* ln_part;           /* fp32 [ln_P][rows][2]: such partials for the rows of x (rows = M if        */
-    int32_t ln_P, ln_axis;         /*   ln_axis 0: x is the A operand; rows = N if ln_axis 1: x is the W operand) */
-    float ln_eps;
-    const void* ln_s;              /* fp32 [N] (axis 0) / [M] (axis 1): row sums of the gamma-scaled weight     */
-    const void* rbias;             /* fp16 [M] per-row bias, axis 1 only (W beta of the swapped product)       */
+    const void* prefetch;          /* optional: range the workgroups touch (at most 1024 128-byte lines each) */
+    int64_t prefetch_bytes;        /*   so it is in the Infinity Cache for a LATER launch (next layers' weights) */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -69,7 +60,7 @@ typedef struct iir_gemm_desc {
 int iir_gemm_f16(const iir_gemm_desc* d, void* stream);
 /* the tile `tile = 0` resolves to for an (M, N, K) problem (paired != 0 for GEGLU / SFT epilogues) */
 int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired);
-/* output-tile width BN of tile id `tile` (1..5), so callers can size `stat_out` */
+/* output-tile width BN of tile id `tile` (1..6) */
 int iir_gemm_tile_bn(int32_t tile);
 
 typedef struct iir_conv_desc {

@@ -31,8 +31,6 @@ class GemmDesc(C.Structure):
         ("out_scale", C.c_float),
         ("tile", C.c_int32),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
-        ("stat_out", C.c_void_p), ("ln_part", C.c_void_p), ("ln_P", C.c_int32), ("ln_axis", C.c_int32),
-        ("ln_eps", C.c_float), ("ln_s", C.c_void_p), ("rbias", C.c_void_p),
     ]
 
 

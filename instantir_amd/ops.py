@@ -69,14 +69,6 @@ def auto_tile(M, N, paired=False, K=0):
     return L.load().iir_gemm_pick_tile(M, N, K, int(paired))
 
 
-def stat_partials(M, N, tile=0, paired=False, K=0):
-    """Number of partial-sum slabs a GEMM with `stat_out` writes: 2 per column tile."""
-    if tile == 0:
-        tile = auto_tile(M, N, paired, K)
-    bn = L.load().iir_gemm_tile_bn(tile)
-    return 2 * ((N + bn - 1) // bn)
-
-
 class _Timed:
     def __init__(self, cls, flops):
         self.cls, self.flops = cls, flops
@@ -105,7 +97,7 @@ def zero_page(device):
 
 
 def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
-         tile=0, prefetch=None, stat_out=None, ln=None):
+         tile=0, prefetch=None):
     """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues)."""
     _chk2d(a, "a"); _chk2d(w, "w"); _chk2d(out, "out")
     M, K = a.shape
@@ -132,11 +124,6 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
-    if stat_out is not None:          # fp32 buffer with >= stat_partials(M, N, tile) * M * 2 elements
-        d.stat_out = stat_out.data_ptr()
-    if ln is not None:                # (partials fp32, P, axis, eps, s fp32, rbias f16 | None): folded LayerNorm
-        part, P, axis, eps, svec, rbias = ln
-        d.ln_part, d.ln_P, d.ln_axis, d.ln_eps, d.ln_s, d.rbias = part.data_ptr(), P, axis, eps, svec.data_ptr(), _p(rbias)
     with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile % 10], 2.0 * M * N * K):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out

@@ -315,67 +315,3 @@ def test_pointwise(dev):
     assert torch.equal(t[:, :40].cpu(), x.T) and t[:, 40:].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
-def test_gemm_layernorm_fold(dev, tile):
-    """LN(x) @ W^T (+b) with the LayerNorm folded into the GEMM (module/min_sdxl.py:534-560): a producer GEMM stores
-    x and emits per-row partial sums; the consumer runs on the RAW x with gamma-scaled weights."""
-    from instantir_amd import ops
-    g = torch.Generator().manual_seed(17 + tile)
-    M, C, N = 300, 256, 192
-    a0, w0 = _rand(g, M, 128), _rand(g, C, 128, scale=0.2)
-    res = _rand(g, M, C) * 2 + 0.5
-    gamma, beta = _rand(g, C) * 0.2 + 1, _rand(g, C) * 0.3
-    W, b = _rand(g, N, C, scale=C ** -0.5), _rand(g, N)
-    # producer: x = a0 @ w0^T + res (stored fp16) + stat_out
-    x = torch.empty(M, C, dtype=torch.half, device=dev)
-    P = ops.stat_partials(M, C, tile)
-    slab = torch.zeros(P * M * 2, dtype=torch.float32, device=dev)
-    ops.gemm(a0.to(dev), w0.to(dev), x, res=res.to(dev), tile=tile, stat_out=slab)
-    torch.cuda.synchronize()
-    xs = x.float().cpu()
-    st = slab.view(P, M, 2).sum(0).cpu()
-    torch.testing.assert_close(st[:, 0], xs.sum(1), rtol=1e-4, atol=1e-2)
-    torch.testing.assert_close(st[:, 1], (xs * xs).sum(1), rtol=1e-4, atol=1e-2)
-    want = F.layer_norm(xs, (C,), gamma.float(), beta.float(), 1e-5) @ W.float().T + b.float()
-    # consumer, axis 0: rows of x are the A operand
-    Wg = (W.float() * gamma.float()[None]).half()
-    s = Wg.float().sum(1)
-    c = (W.float() @ beta.float() + b.float()).half()
-    out = torch.empty(M, N, dtype=torch.half, device=dev)
-    ops.gemm(x, Wg.to(dev), out, bias=c.to(dev), tile=tile, ln=(slab, P, 0, 1e-5, s.to(dev), None))
-    torch.cuda.synchronize()
-    _close(out, want, rtol=4e-3, atol=4e-3, what="ln-fold axis0")
-    # consumer, axis 1: swapped product out^T[n][m] (the V^T form): x is the W operand
-    outT = torch.empty(N, M, dtype=torch.half, device=dev)
-    rb = (W.float() @ beta.float() + b.float()).half()
-    ops.gemm(Wg.to(dev), x, outT, tile=tile, ln=(slab, P, 1, 1e-5, s.to(dev), rb.to(dev)))
-    torch.cuda.synchronize()
-    _close(outT, want.T, rtol=4e-3, atol=4e-3, what="ln-fold axis1")
-
-
-def test_gemm_layernorm_fold_geglu(dev):
-    from instantir_amd import ops
-    from instantir_amd.packing import pair_rows
-    g = torch.Generator().manual_seed(23)
-    M, C, n_out = 200, 128, 256
-    x = (_rand(g, M, C) * 1.5 + 0.2)
-    gamma, beta = _rand(g, C) * 0.2 + 1, _rand(g, C) * 0.3
-    W, b = _rand(g, 2 * n_out, C, scale=C ** -0.5), _rand(g, 2 * n_out)
-    h = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5) @ W.float().T + b.float()
-    want = h[:, :n_out] * F.gelu(h[:, n_out:])
-    # statistics via an identity-like producer: x = x0 @ I  (any GEMM that stores x can emit them)
-    eye = torch.eye(C).half()
-    xd = torch.empty(M, C, dtype=torch.half, device=dev)
-    P = ops.stat_partials(M, C)
-    slab = torch.zeros(P * M * 2, dtype=torch.float32, device=dev)
-    ops.gemm(x.to(dev), eye.to(dev), xd, stat_out=slab)
-    Wg = (W.float() * gamma.float()[None]).half()
-    s = Wg.float().sum(1)
-    c = (W.float() @ beta.float() + b.float()).half()
-    wp = pair_rows(Wg[:n_out], Wg[n_out:]).to(dev)
-    sp = pair_rows(s[:n_out], s[n_out:]).to(dev)
-    cp = pair_rows(c[:n_out], c[n_out:]).to(dev)
-    out = torch.empty(M, n_out, dtype=torch.half, device=dev)
-    ops.gemm(xd, wp, out, bias=cp, epi=ops.EPI_GEGLU, ln=(slab, P, 0, 1e-5, sp, None))
-    torch.cuda.synchronize()
-    _close(out, want, rtol=4e-3, atol=4e-3, what="ln-fold geglu")

@@ -6,7 +6,7 @@ from instantir_amd import ops
 from instantir_amd.packing import conv_weight_nhwc
 
 dev = torch.device("cuda:0")
-TILES = (0, 22, 25, 35)
+TILES = tuple(int(t) for t in os.environ.get('TILES', '0,22,25,35').split(','))
 
 def timeit(fn, iters=20, warm=3):
     for _ in range(warm): fn()
@@ -18,7 +18,7 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 def gemm_bench():
-    shapes = [(2048, 2560, 1280), (4096, 1280, 1280), (8192, 1280, 640), (8192, 640, 640), (8192, 1920, 640), (8192, 5120, 640), (8192, 640, 2560),
+    shapes = [tuple(int(v) for v in sh.split('x')) for sh in os.environ['SHAPES'].split(',')] if 'SHAPES' in os.environ else [(2048, 2560, 1280), (4096, 1280, 1280), (8192, 1280, 640), (8192, 640, 640), (8192, 1920, 640), (8192, 5120, 640), (8192, 640, 2560),
               (2048, 1280, 1280), (2048, 3840, 1280), (2048, 10240, 1280), (2048, 1280, 5120),
               (16384, 5120, 640), (4096, 10240, 1280), (4096, 4096, 4096), (8192, 8192, 8192)]
     for M, N, K in shapes:
