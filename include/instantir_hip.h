@@ -187,6 +187,15 @@ int iir_blend_tiles_f32(const float* a, float* b, int32_t planes, int32_t Ha, in
 
 int iir_transpose_f16(const void* in, int64_t ldi, int32_t rows, int32_t cols, void* out, int64_t ldo, int32_t rows_pad,
                       void* stream);
+/* Measurement hook (bench.py roofline leg; no reference counterpart): arm a start/stop event pair and the NEXT
+ * iir_gemm_f16 / iir_conv2d_nhwc_f16 / iir_attention_d64_f16 launch issued from this thread stamps them with the
+ * kernel's own begin / end timestamps on its stream (hipExtLaunchKernelGGL).  After the stream has drained,
+ * iir_timing_elapsed_us returns that kernel's duration.  Not usable while the stream is being captured. */
+void* iir_timing_event_create(void);
+void iir_timing_event_destroy(void* event);
+int iir_timing_arm(void* start_event, void* stop_event);
+int iir_timing_elapsed_us(void* start_event, void* stop_event, float* us);
+
 int iir_abi_version(void);
 
 #ifdef __cplusplus

@@ -247,6 +247,6 @@ extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
     g.heads = a->heads;
     g.causal = a->causal;
     const dim3 grid(g.npairs * g.qtiles);
-    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    iir_launch(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     return iir_launch_status();
 }

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (CDNA4: wave64, MFMA, 160 KiB LDS/CU).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef _Float16 f16;
@@ -35,6 +36,21 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// Per-launch timing (include/instantir_hip.h: iir_timing_arm): when a start/stop event pair is armed on this thread,
+// the next MFMA-kernel launch goes through hipExtLaunchKernelGGL, which stamps the events with the dispatch's own
+// begin / end timestamps -- the kernel's duration as the profiler sees it, with no event-record barrier in between.
+extern thread_local hipEvent_t iir_armed_start, iir_armed_stop;
+
+template <typename K, typename... Args>
+static inline void iir_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+    if (iir_armed_start) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, iir_armed_start, iir_armed_stop, 0, args...);
+        iir_armed_start = iir_armed_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+    }
 }
 
 static inline int iir_launch_status() {

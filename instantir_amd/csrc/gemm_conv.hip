@@ -362,11 +362,11 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
     if (conv) {
         static bool attr_c = false;
         if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, ST, true, WAVES_M>), grid, block, lds, stream, g);
+        iir_launch(gemm_kernel<BM, BN, ST, true, WAVES_M>, grid, block, lds, stream, g);
     } else {
         static bool attr_g = false;
         if (!attr_g) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, false, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, ST, false, WAVES_M>), grid, block, lds, stream, g);
+        iir_launch(gemm_kernel<BM, BN, ST, false, WAVES_M>, grid, block, lds, stream, g);
     }
     return iir_launch_status();
 }

@@ -105,6 +105,10 @@ SIGNATURES = {
     "iir_prefetch": (C.c_int, [_P, _I64, _I32, _P]),
     "iir_blend_tiles_f32": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "iir_transpose_f16": (C.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I32, _P]),
+    "iir_timing_event_create": (C.c_void_p, []),
+    "iir_timing_event_destroy": (None, [_P]),
+    "iir_timing_arm": (C.c_int, [_P, _P]),
+    "iir_timing_elapsed_us": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "iir_abi_version": (C.c_int, []),
 }
 

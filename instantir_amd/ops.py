@@ -28,34 +28,36 @@ def _chk2d(t, name):
 
 
 class LaunchProfiler:
-    """Optional per-launch timing of the MFMA kernels with HIP events on the launch stream
-    (bench.py's roofline leg).  Records (kernel class, algorithmic FLOPs, start, stop)."""
+    """Optional per-launch timing of the MFMA kernels (bench.py's roofline leg): each launch is issued with a HIP
+    start/stop event pair that the runtime stamps with the kernel's own begin / end timestamps on its stream
+    (`iir_timing_arm`, hipExtLaunchKernelGGL).  Records (kernel class, algorithmic FLOPs, start, stop)."""
 
     def __init__(self):
         self.records = []
+        self._pool = []
 
-    def calibrate(self, n=200):
-        """Queue `n` EMPTY event pairs: their mean interval is what a start/stop pair adds to a bracketed launch (the
-        command processor handles each event as a barrier packet with a timestamped signal)."""
-        self._cal = []
-        for _ in range(n):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); e1.record()
-            self._cal.append((e0, e1))
+    def events(self):
+        h = L.load()
+        e0, e1 = h.iir_timing_event_create(), h.iir_timing_event_create()
+        if not e0 or not e1:
+            raise L.HipLibraryError("hipEventCreate failed")
+        self._pool += [e0, e1]
+        return e0, e1
 
     def summary(self):
         torch.cuda.synchronize()
-        empty = 0.0
-        if getattr(self, "_cal", None):
-            v = sorted(a.elapsed_time(b) for a, b in self._cal)
-            empty = v[len(v) // 2]
-        self.empty_pair_ms = empty
+        h = L.load()
         out = {}
+        us = C.c_float()
         for cls, flops, e0, e1 in self.records:
+            L.check(h.iir_timing_elapsed_us(e0, e1, C.byref(us)), "iir_timing_elapsed_us")
             d = out.setdefault(cls, {"launches": 0, "ms": 0.0, "flops": 0.0})
             d["launches"] += 1
-            d["ms"] += max(e0.elapsed_time(e1) - empty, 0.0)
+            d["ms"] += us.value * 1e-3
             d["flops"] += flops
+        for e in self._pool:
+            h.iir_timing_event_destroy(e)
+        self._pool = []
         return out
 
 
@@ -75,14 +77,12 @@ class _Timed:
 
     def __enter__(self):
         if PROFILER is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
+            e0, e1 = PROFILER.events()
+            L.check(L.load().iir_timing_arm(e0, e1), "iir_timing_arm")
+            PROFILER.records.append((self.cls, self.flops, e0, e1))
 
     def __exit__(self, *a):
-        if PROFILER is not None:
-            self.e1.record()
-            PROFILER.records.append((self.cls, self.flops, self.e0, self.e1))
+        pass
 
 
 _zero_pages = {}
