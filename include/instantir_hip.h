@@ -162,7 +162,13 @@ int iir_unpack_latent(const void* in, int64_t ldi, int32_t R, int32_t C, int32_t
  * {guidance, sqrt(1-abar_t), sqrt(abar_t), k_x0, k_x, k_eps, k_noise, 0}; prev = k_x0*x0 + k_x*x + k_eps*eps
  * + k_noise*noise with x0 = (x - sqrt(1-abar_t)*eps)/sqrt(abar_t).  DDPM: k_eps = 0; DDIM: k_x = 0. */
 int iir_sched_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int32_t HW, int32_t cfg, const float* coef,
-                   const float* x, const float* noise, float* prev, float* x0_out, float* eps_out, void* stream);
+                   const float* x, const float* noise, float* prev, float* x0_out, float* eps_out,
+                   const float* eps_factor, void* stream);
+/* rescale_noise_cfg, pipelines/sdxl_instantir.py:181-192 (used at :1623-1626 when guidance_rescale > 0): per image
+ * factor[b] = phi * std(eps_text) / std(eps_cfg) + (1 - phi) over (C,H,W); iir_sched_step multiplies the guided
+ * eps of image b by eps_factor[b] (NULL = 1).  coef[0] = guidance scale, as for iir_sched_step. */
+int iir_cfg_rescale_factor(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int32_t HW, const float* coef,
+                           float guidance_rescale, float* factor, void* stream);
 
 /* LCMSingleStepScheduler.step, schedulers/lcm_single_step_scheduler.py:455-484.
  * coef = device fp32[4] {sqrt(1-abar_t), sqrt(abar_t), c_out, c_skip}. */

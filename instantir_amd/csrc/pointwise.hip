@@ -82,8 +82,43 @@ __global__ void unpack_latent_kernel(const f16* in, long ldi, int R, int C, int 
 //   x0   = (x - sqrt_beta_t * eps) / sqrt_alpha_t
 //   prev = k_x0 * x0 + k_x * x + k_eps * eps + k_noise * noise
 // coef (device, fp32[8]) = {g, sqrt_beta_t, sqrt_alpha_t, k_x0, k_x, k_eps, k_noise, unused}
+// rescale_noise_cfg (pipelines/sdxl_instantir.py:181-192): per image, over (C, H, W),
+//   factor = phi * std(eps_text) / std(eps_cfg) + (1 - phi),  eps_cfg = u + g * (text - u)   (torch.std: unbiased; the
+// N-1 cancels in the ratio).  One workgroup per image, fp32 element math, fp64 accumulation.
+__global__ __launch_bounds__(1024) void cfg_rescale_kernel(const f16* eps_nhwc, long lde, int B, int C, int HW, const float* coef,
+                                                           float phi, float* factor) {
+    __shared__ double red[4][16];
+    const int b = blockIdx.x;
+    const float g = coef[0];
+    double st = 0., st2 = 0., sc = 0., sc2 = 0.;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x)
+        for (int c = 0; c < C; ++c) {
+            const float u = (float)eps_nhwc[((long)b * HW + p) * lde + c];
+            const float t = (float)eps_nhwc[((long)(B + b) * HW + p) * lde + c];
+            const float e = u + g * (t - u);
+            st += t; st2 += (double)t * t; sc += e; sc2 += (double)e * e;
+        }
+    double v[4] = {st, st2, sc, sc2};
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < 4; ++k) {
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if (lane == 0) red[k][wv] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        double s[4] = {0., 0., 0., 0.};
+        for (int k = 0; k < 4; ++k)
+            for (int w = 0; w < nw; ++w) s[k] += red[k][w];
+        const double n = (double)C * HW;
+        const double var_t = (s[1] - s[0] * s[0] / n) / (n - 1.), var_c = (s[3] - s[2] * s[2] / n) / (n - 1.);
+        factor[b] = (float)((double)phi * sqrt(var_t / var_c) + (1. - (double)phi));
+    }
+}
+
 __global__ void sched_step_kernel(const f16* eps_nhwc, long lde, int B, int C, int HW, int cfg, const float* coef,
-                                  const float* x, const float* noise, float* prev, float* x0_out, float* eps_out) {
+                                  const float* x, const float* noise, float* prev, float* x0_out, float* eps_out,
+                                  const float* eps_factor) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * HW) return;
     const int b = (int)(i / HW), p = (int)(i % HW);
@@ -96,6 +131,7 @@ __global__ void sched_step_kernel(const f16* eps_nhwc, long lde, int B, int C, i
             const float u = (float)eps_nhwc[((long)b * HW + p) * lde + c];
             const float t = (float)eps_nhwc[((long)(B + b) * HW + p) * lde + c];
             e = u + g * (t - u);
+            if (eps_factor) e *= eps_factor[b];
         } else {
             e = (float)eps_nhwc[((long)b * HW + p) * lde + c];
         }
@@ -197,13 +233,23 @@ extern "C" int iir_unpack_latent(const void* in, int64_t ldi, int32_t R, int32_t
     return iir_launch_status();
 }
 
+extern "C" int iir_cfg_rescale_factor(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int32_t HW, const float* coef,
+                                      float guidance_rescale, float* factor, void* stream) {
+    (void)hipGetLastError();
+    if (!eps_nhwc || !coef || !factor || B <= 0 || C <= 0 || HW <= 0 || lde < C || (long)C * HW < 2) return IIR_EINVAL;
+    hipLaunchKernelGGL(cfg_rescale_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, (const f16*)eps_nhwc, (long)lde, B, C, HW,
+                       coef, guidance_rescale, factor);
+    return iir_launch_status();
+}
+
 extern "C" int iir_sched_step(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int32_t HW, int32_t cfg,
                               const float* coef, const float* x, const float* noise, float* prev, float* x0_out,
-                              float* eps_out, void* stream) {
+                              float* eps_out, const float* eps_factor, void* stream) {
     (void)hipGetLastError();
     if (!eps_nhwc || !coef || !x || !prev || B <= 0 || C <= 0 || HW <= 0 || lde < C) return IIR_EINVAL;
+    if (eps_factor && !cfg) return IIR_EINVAL;
     hipLaunchKernelGGL(sched_step_kernel, dim3(nblk((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)eps_nhwc, (long)lde, B, C, HW, cfg, coef, x, noise, prev, x0_out, eps_out);
+                       (const f16*)eps_nhwc, (long)lde, B, C, HW, cfg, coef, x, noise, prev, x0_out, eps_out, eps_factor);
     return iir_launch_status();
 }
 

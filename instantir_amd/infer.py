@@ -135,28 +135,23 @@ def build_pipeline(args, device):
         return pipe, LCMSingleStepScheduler.from_config(pipe.scheduler.config)
     if not args.sdxl_path or not args.instantir_path:
         raise SystemExit("--sdxl_path and --instantir_path are required (or use --synthetic)")
-    cfg, vc = UNetConfig.sdxl(), VAEConfig.sdxl()
-    unet_sd = loaders.load_component(args.sdxl_path, "unet")
+    # infer.py:117-144, call for call
+    print("Initializing pipeline...")
+    pipe = InstantIRPipeline.from_pretrained(args.sdxl_path, torch_dtype=torch.float16, device=device)
     print("Loading LQ-Adapter...")
     adapter = args.adapter_model_path if args.adapter_model_path is not None else os.path.join(args.instantir_path, "adapter.pt")
-    unet_sd = loaders.install_adapter(cfg, unet_sd, adapter)
-    vae = HipVAE(vc, loaders.load_component(args.sdxl_path, "vae"), device)
-    te1 = HipCLIPText(loaders.load_component(args.sdxl_path, "text_encoder"), device, hidden_act="quick_gelu")
-    te2 = HipCLIPText(loaders.load_component(args.sdxl_path, "text_encoder_2"), device, hidden_act="gelu")
-    dino = HipDinov2(loaders._load_file(sorted(g for g in [os.path.join(args.vision_encoder_path, n) for n in ("model.safetensors", "pytorch_model.bin")] if os.path.exists(g))[0]), device)
-    from transformers import CLIPTokenizer
-    tok1 = CLIPTokenizer.from_pretrained(os.path.join(args.sdxl_path, "tokenizer"))
-    tok2 = CLIPTokenizer.from_pretrained(os.path.join(args.sdxl_path, "tokenizer_2"))
-    mk = lambda t: (lambda texts: t(texts, padding="max_length", max_length=t.model_max_length, truncation=True, return_tensors="pt").input_ids)
-    pipe = InstantIRPipeline(cfg, unet_sd, scheduler=DDPMScheduler(), vae=vae, device=device, image_encoder=dino,
-                             text_encoder=te1, text_encoder_2=te2, tokenizer=mk(tok1), tokenizer_2=mk(tok2))
+    # (the reference parses --adapter_tokens but never forwards it, infer.py:124-129,269; forwarded here: default 64 is the same call)
+    loaders.load_adapter_to_pipe(pipe, adapter, args.vision_encoder_path, use_clip_encoder=args.use_clip_encoder,
+                                 adapter_tokens=args.adapter_tokens)
     lora_path = args.previewer_lora_path if args.previewer_lora_path is not None else args.instantir_path
-    lora, alpha = loaders.read_previewer_lora(lora_path)
-    lora_alpha = pipe.prepare_previewers(lora, lora_alpha=alpha)
+    lora_alpha = pipe.prepare_previewers(lora_path)
     print(f"use lora alpha {lora_alpha}")
+    pipe.scheduler = DDPMScheduler.from_pretrained(args.sdxl_path, subfolder="scheduler") \
+        if os.path.isfile(os.path.join(args.sdxl_path, "scheduler", "scheduler_config.json")) else DDPMScheduler()
+    lcm_scheduler = LCMSingleStepScheduler.from_config(pipe.scheduler.config)
     print("Loading checkpoint...")
     pipe.aggregator.load_state_dict(loaders.read_aggregator(os.path.join(args.instantir_path, "aggregator.pt")))
-    return pipe, LCMSingleStepScheduler.from_config(pipe.scheduler.config)
+    return pipe, lcm_scheduler
 
 
 def main(args, device):

@@ -98,7 +98,8 @@ SIGNATURES = {
     "iir_copy_add_f16": (C.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _I32, _P]),
     "iir_pack_latent": (C.c_int, [_P, _I32, _I32, _I32, _P, _I64, _I32, _F, _P]),
     "iir_unpack_latent": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
-    "iir_sched_step": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "iir_sched_step": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "iir_cfg_rescale_factor": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _F, _P, _P]),
     "iir_lcm_step": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P]),
     "iir_sched_step_f32": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P]),
     "iir_axpby_f32": (C.c_int, [_P, _P, _P, _I64, _P, _P]),

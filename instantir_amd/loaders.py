@@ -13,14 +13,16 @@ only with loaders that execute nothing from the file: safetensors, or `torch.loa
 """
 from __future__ import annotations
 
+import dataclasses
 import glob
+import json
 import os
 from collections import OrderedDict
 from typing import Dict, List, Tuple
 
 import torch
 
-from .config import UNetConfig
+from .config import ResamplerConfig, UNetConfig, VAEConfig
 
 
 def _load_file(path: str) -> Dict[str, torch.Tensor]:
@@ -155,3 +157,92 @@ def read_previewer_lora(path_or_dict, weight_name="previewer_lora_weights.bin") 
 
 def read_aggregator(path: str) -> Dict[str, torch.Tensor]:
     return _load_file(path)
+
+
+# ---- configs from the checkpoint directories / tensors ----------------------------------------------------------------
+def _read_json(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def unet_config_from_dir(model_dir: str) -> UNetConfig:
+    """`<model_dir>/unet/config.json` (diffusers `UNet2DConditionModel` config) -> UNetConfig; SDXL-base values when the
+    file is absent.  Only SDXL-family layouts are accepted: DownBlock2D first, head_dim 64, text_time addition embedding."""
+    path = os.path.join(model_dir, "unet", "config.json")
+    if not os.path.isfile(path):
+        return UNetConfig.sdxl()
+    c = _read_json(path)
+    boc = tuple(c["block_out_channels"])
+    types = c.get("down_block_types", ["DownBlock2D"] + ["CrossAttnDownBlock2D"] * (len(boc) - 1))
+    tl = c.get("transformer_layers_per_block", 1)
+    tl = [tl] * len(boc) if isinstance(tl, int) else list(tl)
+    depth = tuple(tl[i] if "CrossAttn" in types[i] else 0 for i in range(len(boc)))
+    ahd = c.get("attention_head_dim", 8)
+    ahd = [ahd] * len(boc) if isinstance(ahd, int) else list(ahd)       # SDXL stores the HEAD COUNT per block here
+    for i, d in enumerate(depth):
+        if d > 0 and boc[i] // ahd[i] != 64:
+            raise ValueError(f"unet/config.json: block {i} has head_dim {boc[i] // ahd[i]}; the HIP attention kernel is head_dim 64")
+    if c.get("addition_embed_type", "text_time") != "text_time":
+        raise ValueError("unet/config.json: only addition_embed_type 'text_time' (SDXL) is supported")
+    ate = c.get("addition_time_embed_dim", 256)
+    base = UNetConfig.sdxl()
+    return dataclasses.replace(
+        base, in_channels=c.get("in_channels", 4), out_channels=c.get("out_channels", 4), block_out_channels=boc,
+        transformer_depth=depth, layers_per_block=c.get("layers_per_block", 2), cross_attention_dim=c.get("cross_attention_dim", 2048),
+        addition_time_embed_dim=ate, pooled_dim=c.get("projection_class_embeddings_input_dim", 2816) - 6 * ate,
+        norm_groups=c.get("norm_num_groups", 32))
+
+
+def vae_config_from_dir(model_dir: str) -> VAEConfig:
+    path = os.path.join(model_dir, "vae", "config.json")
+    if not os.path.isfile(path):
+        return VAEConfig.sdxl()
+    c = _read_json(path)
+    return VAEConfig(in_channels=c.get("in_channels", 3), latent_channels=c.get("latent_channels", 4),
+                     block_out_channels=tuple(c["block_out_channels"]), layers_per_block=c.get("layers_per_block", 2),
+                     norm_groups=c.get("norm_num_groups", 32), scaling_factor=c.get("scaling_factor", 0.13025))
+
+
+def resampler_config_from_state(image_proj: Dict[str, torch.Tensor], seq_len: int = 257) -> ResamplerConfig:
+    """Geometry of the Resampler from its own tensors (module/ip_adapter/resampler.py:81-125); dim_head is 64 there."""
+    q, dim = image_proj["latents"].shape[1:]
+    depth = 1 + max(int(k.split(".")[1]) for k in image_proj if k.startswith("layers."))
+    inner = image_proj["layers.0.0.to_q.weight"].shape[0]
+    return ResamplerConfig(dim=dim, depth=depth, dim_head=64, heads=inner // 64, num_queries=q,
+                           embedding_dim=image_proj["proj_in.weight"].shape[1], output_dim=image_proj["proj_out.weight"].shape[0],
+                           ff_mult=image_proj["layers.0.1.1.weight"].shape[0] // dim, seq_len=seq_len)
+
+
+def load_adapter_to_pipe(pipe, pretrained_model_path_or_dict, image_encoder_or_path=None, feature_extractor_or_path=None,
+                         use_clip_encoder=False, adapter_tokens=64, use_lcm=False, use_adaln=True):
+    """`module/ip_adapter/utils.py:73-161` for this build's pipeline: installs the TA-IP processors + Resampler into the UNet
+    state (the nets are packed lazily, at the first call) and attaches the DINOv2 image encoder (a `HipDinov2`, or a
+    directory holding `model.safetensors` / `pytorch_model.bin` [+ config.json]).  `feature_extractor_or_path` is accepted
+    and ignored: the fixed DINOv2 preprocessing lives in `encoders.dinov2_preprocess`."""
+    if use_clip_encoder:
+        raise NotImplementedError("use_clip_encoder: only the DINOv2 image-encoder branch is built")
+    if not use_adaln:
+        raise NotImplementedError("use_adaln=False (IPAttnProcessor2_0 without AdaLayerNorm) is not built")
+    ad = read_adapter(pretrained_model_path_or_dict)
+    rc = resampler_config_from_state(ad["image_proj"], seq_len=pipe.cfg.resampler.seq_len)
+    if rc.num_queries != adapter_tokens:
+        raise ValueError(f"adapter has {rc.num_queries} image tokens, adapter_tokens={adapter_tokens}")
+    pipe.cfg = dataclasses.replace(pipe.cfg, resampler=rc, num_ip_tokens=rc.num_queries)
+    pipe._unet_sd = install_adapter(pipe.cfg, pipe._unet_sd, ad)
+    pipe._unet = pipe._unet_prev = None
+    if image_encoder_or_path is not None:
+        if isinstance(image_encoder_or_path, str):
+            from .encoders import HipDinov2
+            cands = [os.path.join(image_encoder_or_path, n) for n in ("model.safetensors", "pytorch_model.bin")]
+            found = [c for c in cands if os.path.exists(c)]
+            if not found:
+                raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {image_encoder_or_path}")
+            kw = {}
+            cj = os.path.join(image_encoder_or_path, "config.json")
+            if os.path.isfile(cj):
+                c = _read_json(cj)
+                kw = {"patch_size": c.get("patch_size", 14), "num_heads": c.get("num_attention_heads"), "eps": c.get("layer_norm_eps", 1e-6)}
+            pipe.image_encoder = HipDinov2(_load_file(found[0]), pipe.device, **kw)
+        else:
+            pipe.image_encoder = image_encoder_or_path
+    return pipe

@@ -287,12 +287,20 @@ def unpack_latent(x2d, out):
     return out
 
 
-def sched_step(eps2d, B, coef, x, prev, noise=None, cfg=True, x0_out=None, eps_out=None):
+def sched_step(eps2d, B, coef, x, prev, noise=None, cfg=True, x0_out=None, eps_out=None, eps_factor=None):
     _, Cc, H, Wd = x.shape
     L.check(L.load().iir_sched_step(eps2d.data_ptr(), eps2d.stride(0), B, Cc, H * Wd, int(cfg), coef.data_ptr(),
-                                    x.data_ptr(), _p(noise), prev.data_ptr(), _p(x0_out), _p(eps_out), _stream()),
-            "iir_sched_step")
+                                    x.data_ptr(), _p(noise), prev.data_ptr(), _p(x0_out), _p(eps_out), _p(eps_factor),
+                                    _stream()), "iir_sched_step")
     return prev
+
+
+def cfg_rescale_factor(eps2d, B, coef, x, guidance_rescale, factor):
+    """factor (B,) fp32 device: the per-image multiplier `rescale_noise_cfg` applies to the guided eps."""
+    _, Cc, H, Wd = x.shape
+    L.check(L.load().iir_cfg_rescale_factor(eps2d.data_ptr(), eps2d.stride(0), B, Cc, H * Wd, coef.data_ptr(),
+                                            float(guidance_rescale), factor.data_ptr(), _stream()), "iir_cfg_rescale_factor")
+    return factor
 
 
 def lcm_step(eps2d, B, rep, coef, x, out2d, out_nchw=None):

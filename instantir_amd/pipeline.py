@@ -16,6 +16,7 @@ Latents are carried in fp32 between steps (the reference carries fp16); UNet inp
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Callable, Dict, List, Optional
 
@@ -40,6 +41,10 @@ class _AggregatorHandle:
 
     def load_state_dict(self, sd, strict=True):
         from .weights import aggregator_specs
+        k = "controlnet_mid_block.0.mlp_shared.0.weight"            # SFT hidden width comes from the file (module/aggregator.py:60)
+        if k in sd and sd[k].shape[0] != self._pipe.cfg.sft_hidden:
+            import dataclasses
+            self._pipe.cfg = dataclasses.replace(self._pipe.cfg, sft_hidden=sd[k].shape[0])
         want = {n for n, _, _ in aggregator_specs(self._pipe.cfg)}
         missing, unexpected = sorted(want - set(sd)), sorted(set(sd) - want)
         if strict and (missing or unexpected):
@@ -78,6 +83,41 @@ class InstantIRPipeline:
         self._guidance_scale = 7.0
 
     # ---- reference surface ----------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, device="cuda:0", **kwargs):
+        """`InstantIRPipeline.from_pretrained(sdxl_dir, torch_dtype=torch.float16)` (infer.py:117-120): reads the SDXL
+        directory layout with this build's own readers -- `unet/`, `vae/`, `text_encoder(_2)/`
+        safetensors (+ config.json), `tokenizer(_2)/`.  Local directories only: there is no hub access.  The TA-IP
+        adapter, previewer LoRA and Aggregator are attached afterwards exactly as infer.py does
+        (`loaders.load_adapter_to_pipe`, `prepare_previewers`, `aggregator.load_state_dict`).  Compute is fp16 with
+        fp32 accumulation whatever `torch_dtype` says."""
+        from . import loaders
+        from .encoders import HipCLIPText
+        from .vae import HipVAE
+        d = pretrained_model_name_or_path
+        if not os.path.isdir(d):
+            raise FileNotFoundError(f"{d!r} is not a local directory (hub ids cannot be fetched: no network)")
+        cfg, vc = loaders.unet_config_from_dir(d), loaders.vae_config_from_dir(d)
+        unet_sd = loaders.load_component(d, "unet")
+        vae = HipVAE(vc, loaders.load_component(d, "vae"), device) if os.path.isdir(os.path.join(d, "vae")) else None
+        enc, tok = [], []
+        for sub, tsub, default_act in (("text_encoder", "tokenizer", "quick_gelu"), ("text_encoder_2", "tokenizer_2", "gelu")):
+            e = t = None
+            if os.path.isdir(os.path.join(d, sub)):
+                cj = os.path.join(d, sub, "config.json")
+                c = loaders._read_json(cj) if os.path.isfile(cj) else {}
+                e = HipCLIPText(loaders.load_component(d, sub), device, hidden_act=c.get("hidden_act", default_act),
+                                eos_token_id=c.get("eos_token_id", 2), eps=c.get("layer_norm_eps", 1e-5))
+            if os.path.isdir(os.path.join(d, tsub)):
+                from transformers import CLIPTokenizer
+                tk = CLIPTokenizer.from_pretrained(os.path.join(d, tsub))
+                t = (lambda tk_: (lambda texts: tk_(texts, padding="max_length", max_length=tk_.model_max_length, truncation=True,
+                                                    return_tensors="pt").input_ids))(tk)
+            enc.append(e)
+            tok.append(t)
+        return cls(cfg, unet_sd, scheduler=kwargs.get("scheduler"), vae=vae, device=device, text_encoder=enc[0],
+                   text_encoder_2=enc[1], tokenizer=tok[0], tokenizer_2=tok[1])
+
     def to(self, *a, **k):
         return self
 
@@ -96,6 +136,14 @@ class InstantIRPipeline:
         `convert_unet_state_dict_to_peft` and the `attn2` -> `attn2.processor` rename (:364-370).
         Raises ValueError on keys that match no LoRA target (:390-394); missing keys are ignored."""
         targets = LCM_LORA_MODULES if use_lcm else PREVIEWER_LORA_MODULES
+        if isinstance(lora_state_dict, (str, os.PathLike)):          # the reference's own call form: a directory / file path
+            from .loaders import read_previewer_lora
+            lora_state_dict, file_alpha = read_previewer_lora(os.fspath(lora_state_dict))
+            lora_alpha = file_alpha if lora_alpha is None else lora_alpha
+        ranks = {v.shape[0] for k, v in lora_state_dict.items() if k.endswith(".lora_A.weight")}
+        if len(ranks) == 1 and next(iter(ranks)) != self.cfg.lora_rank:
+            import dataclasses
+            self.cfg = dataclasses.replace(self.cfg, lora_rank=next(iter(ranks)))
         unexpected = []
         for k in lora_state_dict:
             for suf in (".lora_A.weight", ".lora_B.weight"):
@@ -298,8 +346,6 @@ class InstantIRPipeline:
         if multistep_restore:
             raise NotImplementedError("multistep_restore passes kwargs the shipped DDPM scheduler does not accept "
                                       "(SURVEY.md Appendix C Q5)")
-        if guidance_rescale and guidance_rescale > 0.0:
-            raise NotImplementedError("guidance_rescale > 0 is not on the benchmarked path (default 0.0)")
         if prompt is None and prompt_embeds is None and kwargs.get("prompt_ids") is not None and self.text_encoder is not None:
             prompt_embeds_chk = kwargs["prompt_ids"]          # ids stand in for the prompt in the exclusivity checks
         else:
@@ -400,7 +446,8 @@ class InstantIRPipeline:
             x = latents.to(dev, torch.float32) * self.scheduler.init_noise_sigma
         x = x.contiguous()
 
-        loop = _DenoiseLoop(self, B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler)
+        loop = _DenoiseLoop(self, B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler,
+                            guidance_rescale=guidance_rescale)
         preview_row = []
         preview_factor = torch.ones(B)
         for i, t in enumerate(ts):
@@ -450,8 +497,10 @@ class _DenoiseLoop:
     Three phases exist (pipelines/sdxl_instantir.py:1542-1616): "preview" (UNet+LoRA -> LCM preview
     -> Aggregator -> UNet), "agg" (Aggregator on the LQ / reference latent -> UNet), "unet"."""
 
-    def __init__(self, pipe, B, rep, H, W, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler):
+    def __init__(self, pipe, B, rep, H, W, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler, guidance_rescale=0.0):
         dev = pipe.device
+        self.guidance_rescale = float(guidance_rescale or 0.0)
+        self.cfg_factor = torch.ones(B, dtype=torch.float32, device=dev)
         self.p, self.B, self.rep, self.H, self.W = pipe, B, rep, H, W
         self.st, self.st_prev, self.st_agg = st, st_prev, st_agg
         self.prev_sched = previewer_scheduler
@@ -513,8 +562,7 @@ class _DenoiseLoop:
             down, mid = p._agg.forward(self.lq16, cond, self.t_dev, self.st_agg)
             main.wait_event(join)
             eps = p._unet.decode(enc, self.st, down, mid, self.res_scale)
-            ops.sched_step(eps, B, self.sched_coef, self.x_in, self.x_out, noise=self.noise if use_noise else None,
-                           cfg=rep == 2, x0_out=self.x0 if want_x0 else None)
+            self._sched(eps, use_noise, want_x0)
             return
         if mode != "unet":
             if mode == "preview":
@@ -526,8 +574,16 @@ class _DenoiseLoop:
                 cond = self.ref16 if self.ref16 is not None else self.lq16               # :1579-1582
             down, mid = p._agg.forward(self.lq16, cond, self.t_dev, self.st_agg)           # :1591-1599
         eps = p._unet.forward(self.lat16, self.t_dev, self.st, down, mid, self.res_scale if down is not None else None)
+        self._sched(eps, use_noise, want_x0)
+
+    def _sched(self, eps, use_noise, want_x0):
+        """CFG (+ rescale_noise_cfg when guidance_rescale > 0, :181-192) + scheduler step, :1619-1633."""
+        B, rep = self.B, self.rep
+        fac = None
+        if rep == 2 and self.guidance_rescale > 0.0:
+            fac = ops.cfg_rescale_factor(eps, B, self.sched_coef, self.x_in, self.guidance_rescale, self.cfg_factor)
         ops.sched_step(eps, B, self.sched_coef, self.x_in, self.x_out, noise=self.noise if use_noise else None,
-                       cfg=rep == 2, x0_out=self.x0 if want_x0 else None)                 # :1619-1633
+                       cfg=rep == 2, x0_out=self.x0 if want_x0 else None, eps_factor=fac)
 
     def step(self, mode, t, x, res_scale_rows, guidance, eta, noise, generator, want_x0=False, want_preview=False):
         p, R = self.p, self.B * self.rep

@@ -69,6 +69,19 @@ class _Base:
         self.timesteps = torch.from_numpy(np.arange(0, cfg["num_train_timesteps"])[::-1].copy().astype(np.int64))
 
     @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, **kw):
+        """`DDPMScheduler.from_pretrained(sdxl_path, subfolder="scheduler")` (infer.py:137): reads
+        `<dir>[/<subfolder>]/scheduler_config.json`; local directories only."""
+        import json
+        import os
+        d = os.path.join(pretrained_model_name_or_path, subfolder) if subfolder else pretrained_model_name_or_path
+        path = os.path.join(d, "scheduler_config.json")
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"{path} not found (hub ids cannot be fetched: no network)")
+        with open(path) as f:
+            return cls.from_config(json.load(f), **kw)
+
+    @classmethod
     def from_config(cls, config, **kw):
         import inspect
         names = set(_SDXL_DEFAULTS) | (set(inspect.signature(cls.__init__).parameters) - {"self", "kw"})

@@ -13,7 +13,8 @@ from . import nets, sched
 def denoise(P, PA, lora, cfg, lq, prompt_embeds, pooled, image_embeds, *, negative_prompt_embeds=None,
             negative_pooled=None, num_inference_steps=30, guidance_scale=7.0, sampler="ddim", eta=0.0,
             init_noise=None, step_noises=None, controlnet_conditioning_scale=1.0, control_guidance_start=0.0,
-            control_guidance_end=1.0, preview_start=0.0, preview_end=1.0, use_previewer=True, trace=None):
+            control_guidance_end=1.0, preview_start=0.0, preview_end=1.0, use_previewer=True, trace=None,
+            guidance_rescale=0.0):
     """Returns the final latents (B,4,h,w).  `lq`: LQ latent (B,4,h,w); `image_embeds`: (2,B,S,E) [neg;pos] under CFG
     (pipelines/sdxl_instantir.py:700-707) else (1,B,S,E).  `trace` (dict) collects per-step tensors when given."""
     B = lq.shape[0]
@@ -57,6 +58,10 @@ def denoise(P, PA, lora, cfg, lq, prompt_embeds, pooled, image_embeds, *, negati
         if do_cfg:                                                           # :1619-1621
             u, c = eps.chunk(2)
             eps = u + guidance_scale * (c - u)
+            if guidance_rescale > 0.0:                                       # rescale_noise_cfg, :181-192 (called at :1623-1626)
+                dims = list(range(1, c.ndim))
+                std_text, std_cfg = c.std(dim=dims, keepdim=True), eps.std(dim=dims, keepdim=True)
+                eps = guidance_rescale * (eps * (std_text / std_cfg)) + (1 - guidance_rescale) * eps
         if sampler == "ddim":
             x_next, x0 = sched.ddim_step(acp, eps, t, x, n, eta=eta, noise=None if step_noises is None else step_noises[i])
         else:

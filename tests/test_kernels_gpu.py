@@ -284,6 +284,32 @@ def test_adaln_batch_matches_single_launches(dev):
     _close(jobs[0][1], want.reshape(R * nip, 128).cpu(), what="adaLN batch")
 
 
+def test_cfg_rescale_factor(dev):
+    """iir_cfg_rescale_factor + eps_factor of iir_sched_step == rescale_noise_cfg (pipelines/sdxl_instantir.py:181-192)."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, H, Wd, phi, gs = 3, 12, 20, 0.7, 6.5
+    eps = (_rand(g, 2 * B * H * Wd, 64) * 1.3)
+    eps_d = eps.to(dev)
+    x = torch.randn(B, 4, H, Wd, generator=g)
+    coef = torch.tensor([gs, 0.6, 0.8, 0.0, 0.0, 1.0, 0.0, 0.0], device=dev)       # prev = eps (k_eps = 1): exposes the guided eps
+    fac = torch.zeros(B, device=dev)
+    ops.cfg_rescale_factor(eps_d, B, coef, x.to(dev), phi, fac)
+    e4 = eps.float()[:, :4].reshape(2, B, H * Wd, 4).permute(0, 1, 3, 2).reshape(2, B, 4, H, Wd)
+    u, c = e4[0], e4[1]
+    cfg_ = u + gs * (c - u)
+    dims = [1, 2, 3]
+    ratio = c.std(dim=dims, keepdim=True) / cfg_.std(dim=dims, keepdim=True)
+    want_fac = (phi * ratio + (1 - phi)).reshape(B)
+    torch.cuda.synchronize()
+    assert torch.allclose(fac.cpu(), want_fac, rtol=1e-5, atol=1e-6)
+    prev = torch.empty(B, 4, H, Wd, device=dev)
+    ops.sched_step(eps_d, B, coef, x.to(dev), prev, cfg=True, eps_factor=fac)
+    torch.cuda.synchronize()
+    want = phi * (cfg_ * ratio) + (1 - phi) * cfg_
+    assert torch.allclose(prev.cpu(), want, rtol=1e-5, atol=1e-5)
+
+
 def test_pointwise(dev):
     from instantir_amd import ops
     g = torch.Generator().manual_seed(8)

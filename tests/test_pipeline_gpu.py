@@ -93,6 +93,20 @@ def test_ddpm_phases_loop(env):
     assert torch.isfinite(got).all() and p >= 40, p
 
 
+def test_guidance_rescale_loop(env):
+    """guidance_rescale > 0: rescale_noise_cfg (pipelines/sdxl_instantir.py:181-192,1623-1626) inside the fused CFG + step."""
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    kw = dict(num_inference_steps=4, guidance_scale=7.0, guidance_rescale=0.7)
+    want = _oracle(cfg, sd, sda, lora, inp, sampler="ddim", **kw)
+    plain = _oracle(cfg, sd, sda, lora, inp, sampler="ddim", num_inference_steps=4, guidance_scale=7.0)
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    got = _call(pipe, inp, **kw)
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p >= 40, p
+    assert psnr(got, plain) < p - 6          # the rescale is live: clearly closer to the rescaled oracle than to the plain one
+
+
 def test_no_cfg_single_image(env):
     """BASELINE config 1 shape of the control flow: cfg = 1.0 (no CFG doubling), 4 steps."""
     from instantir_amd.schedulers import DDIMScheduler
