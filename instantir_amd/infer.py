@@ -80,6 +80,14 @@ def plan_batches(test_path, out_dir, batch_size):
     return batches
 
 
+def shard_batches(batches, rank, world):
+    """Multi-GPU (SURVEY.md section 8e): the batch list infer.py:151-169 forms is cut into contiguous per-rank slices;
+    images never interact, so each rank runs the whole loop on its slice and there is no per-step collective."""
+    from .parallel import shard_range
+    lo, hi = shard_range(len(batches), rank, world)
+    return batches[lo:hi]
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="InstantIR restoration on MI355X")
     p.add_argument("--sdxl_path", type=str, default=None)
@@ -154,13 +162,14 @@ def build_pipeline(args, device):
     return pipe, lcm_scheduler
 
 
-def main(args, device):
+def main(args, device, rank=0, world=1):
     pipe, lcm_scheduler = build_pipeline(args, device)
     post_fix = f"_{args.post_fix}" if args.post_fix else ""
     out_dir = f"{args.out_path}/{post_fix}"
     os.makedirs(out_dir, exist_ok=True)
     cfg = pipe.cfg
-    for lq_batch in plan_batches(args.test_path, os.path.join(args.out_path, post_fix), args.batch_size):
+    batches = plan_batches(args.test_path, os.path.join(args.out_path, post_fix), args.batch_size)
+    for lq_batch in shard_batches(batches, rank, world):
         generator = torch.Generator(device=device).manual_seed(args.seed)                # infer.py:172: fresh per batch
         lq, out_sizes = [], []
         for name in lq_batch:
@@ -193,4 +202,10 @@ if __name__ == "__main__":
     a = build_parser().parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("instantir_amd.infer needs an MI355X: the restoration path has no CPU fallback")
-    main(a, torch.device("cuda:0"))
+    # one process per GPU: `python -m torch.distributed.run --nproc-per-node N -m instantir_amd.infer ...` shards the inputs
+    from .parallel import barrier, init_from_env
+    rank_, world_, _, dev_ = init_from_env()
+    main(a, dev_, rank_, world_)
+    if world_ > 1:
+        barrier()
+        torch.distributed.destroy_process_group()

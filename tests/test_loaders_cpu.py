@@ -127,3 +127,18 @@ def test_resize_img_and_batches(tmp_path):
     a = build_parser().parse_args(["--test_path", "x"])
     assert (a.num_inference_steps, a.cfg, a.creative_start, a.preview_start, a.batch_size, a.seed, a.denoising_start) == \
         (30, 7.0, 1.0, 0.0, 6, 42, 1000)
+
+
+def test_batches_shard_over_ranks_without_overlap(tmp_path):
+    """contiguous split of infer.py's batch list; every image restored exactly once."""
+    from instantir_amd.infer import plan_batches, shard_batches
+    src, out = tmp_path / "in", tmp_path / "out"
+    src.mkdir(); out.mkdir()
+    for i in range(11):
+        (src / f"{i:02d}.png").write_bytes(b"")
+    (out / "03.png").write_bytes(b"")                       # already restored: skipped before sharding
+    batches = plan_batches(str(src), str(out), 2)
+    assert sum(len(b) for b in batches) == 10 and ["03.png"] not in batches
+    for world in (1, 2, 3, 8):
+        got = [b for r in range(world) for b in shard_batches(batches, r, world)]
+        assert got == batches
