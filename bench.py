@@ -185,8 +185,18 @@ def main():
         name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = d["ms"] / d["launches"]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # HBM-side bytes per launch of that class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+        # separately over this same command, corrected as MI355X_MICROARCH.md prescribes: profiles/*_pmc_traffic.json)
+        traffic = None
+        if not args.tiny and args.size == 1024:
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            pm = sorted(p_ for p_ in os.listdir(pdir) if p_.endswith("_pmc_traffic.json")) if os.path.isdir(pdir) else []
+            if pm:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pm[-1])) as f:
+                    traffic = json.load(f)["classes"].get(name, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(ach / 2500.0, 4), "traffic": None, "launches_per_step": d["launches"] // 2,
+                "frac": round(ach / 2500.0, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)",
+                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "launches_per_step": d["launches"] // 2,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "timing": "hipExtLaunchKernelGGL start/stop events (kernel begin/end timestamps)",
                 "classes": {k: {"launches_per_step": v["launches"] // 2, "ms_per_step": round(v["ms"] / 2, 3),
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in sorted(summ.items())}}

@@ -348,15 +348,23 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     const size_t lds = ST * (BM + BN) * BK * sizeof(f16) + 1024;   // ring (reused as the output tile) + prefetch scratch
-    // pick the XCD partition with the least per-L2 operand rows: (tiles_m/xm)*BM + (tiles_n/xn)*BN
-    long best = -1;
+    // pick the XCD partition (xm x 8/xm rectangles of the tile grid) with the least bytes each 4 MiB L2 pulls over the
+    // fabric.  Inside a rectangle tiles walk M fastest, ~64 workgroups are resident per XCD, so its rm x BM rows of A are
+    // re-used by successive groups of N-tile columns: if they fit the L2 they are read once, otherwise once per group.
+    // (PMC: the 128x160 GEMM class read 137 MB per launch against 52 MB of operands; kbench 16384x5120x640: 615 -> 679 TFLOP/s)
+    double best = -1.;
     static const int force_xm = getenv("IIR_XM") ? atoi(getenv("IIR_XM")) : 0;   // tuning knob: 1,2,4,8 forces the split
+    const double row_bytes = (double)g.K * 2.;
     for (int xm = 1; xm <= 8; xm *= 2) {
         if (force_xm && xm != force_xm) continue;
         const int xn = 8 / xm;
         const int rm = (g.tiles_m + xm - 1) / xm, rn = (g.tiles_n + xn - 1) / xn;
-        const long cost = (long)rm * BM + (long)rn * BN + ((long)rm * rn * 8 - (long)g.tiles_m * g.tiles_n) * 8;
-        if (best < 0 || cost < best) { best = cost; g.xm = xm; g.rm = rm; g.rn = rn; }
+        const double a_bytes = (double)rm * BM * row_bytes, w_bytes = (double)rn * BN * row_bytes;
+        const int cols_per_group = rm >= 64 ? 1 : 64 / rm;
+        const double groups = (double)((rn + cols_per_group - 1) / cols_per_group);
+        double cost = (a_bytes <= 3.0 * 1048576. ? a_bytes : a_bytes * groups) + w_bytes;
+        cost += ((double)rm * rn * 8 - (double)g.tiles_m * g.tiles_n) * 8. * BK * (BM + BN);     // padding workgroups of ragged rectangles
+        if (best < 0. || cost < best) { best = cost; g.xm = xm; g.rm = rm; g.rn = rn; }
     }
     const dim3 grid(8 * g.rm * g.rn), block(128 * WAVES_M);
     if (conv) {

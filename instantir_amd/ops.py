@@ -49,12 +49,13 @@ class LaunchProfiler:
         h = L.load()
         out = {}
         us = C.c_float()
-        for cls, flops, e0, e1 in self.records:
+        for cls, flops, e0, e1, nbytes in self.records:
             L.check(h.iir_timing_elapsed_us(e0, e1, C.byref(us)), "iir_timing_elapsed_us")
-            d = out.setdefault(cls, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d = out.setdefault(cls, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += us.value * 1e-3
             d["flops"] += flops
+            d["bytes"] += nbytes
         for e in self._pool:
             h.iir_timing_event_destroy(e)
         self._pool = []
@@ -72,14 +73,14 @@ def auto_tile(M, N, paired=False, K=0):
 
 
 class _Timed:
-    def __init__(self, cls, flops):
-        self.cls, self.flops = cls, flops
+    def __init__(self, cls, flops, nbytes=0.0):
+        self.cls, self.flops, self.nbytes = cls, flops, nbytes      # algorithmic FLOPs and bytes (each operand once)
 
     def __enter__(self):
         if PROFILER is not None:
             e0, e1 = PROFILER.events()
             L.check(L.load().iir_timing_arm(e0, e1), "iir_timing_arm")
-            PROFILER.records.append((self.cls, self.flops, e0, e1))
+            PROFILER.records.append((self.cls, self.flops, e0, e1, self.nbytes))
 
     def __exit__(self, *a):
         pass
@@ -124,7 +125,9 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
-    with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile % 10], 2.0 * M * N * K):
+    No = N // 2 if epi != EPI_PLAIN else N
+    with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile % 10], 2.0 * M * N * K,
+                2.0 * (M * K + N * K + M * No + (M * No if res is not None else 0))):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out
 
@@ -163,7 +166,9 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
     d.x_img_stride, d.y_img_rows, d.res_img_rows, d.pad_mode = x.stride(0), y_img_rows, res_img_rows, pad_mode
-    with _Timed("gemm_kernel<%s,conv>" % _TILE_NAMES[tile % 10], 2.0 * Mo * Cout * ksize * ksize * Cin):
+    Co = Cout // 2 if epi != EPI_PLAIN else Cout
+    with _Timed("gemm_kernel<%s,conv>" % _TILE_NAMES[tile % 10], 2.0 * Mo * Cout * ksize * ksize * Cin,
+                2.0 * (R * H * Wd * Cin + Cout * ksize * ksize * Cin + Mo * Co + (Mo * Co if res is not None else 0))):
         L.check(L.load().iir_conv2d_nhwc_f16(C.byref(d), _stream()), "iir_conv2d_nhwc_f16")
     return out
 
@@ -182,7 +187,8 @@ def attention(q, o, kv, batch, heads, Tq, scale=0.125, causal=False):
         d.kv[i].K, d.kv[i].ldk, d.kv[i].k_batch_stride = k.data_ptr(), k.stride(0), k_rows * k.stride(0)
         d.kv[i].Vt, d.kv[i].ldvt, d.kv[i].vt_batch_stride = vt.data_ptr(), vt.stride(0), vbs
         d.kv[i].Tkv = tkv
-    with _Timed("attn_kernel", 4.0 * batch * heads * Tq * 64 * sum(k[4] for k in kv)):
+    with _Timed("attn_kernel", 4.0 * batch * heads * Tq * 64 * sum(k[4] for k in kv),
+                2.0 * batch * heads * 64 * (2 * Tq + 2 * sum(k[4] for k in kv))):
         L.check(L.load().iir_attention_d64_f16(C.byref(d), _stream()), "iir_attention_d64_f16")
     return o
 
