@@ -51,6 +51,8 @@ typedef struct iir_gemm_desc {
     int32_t tile;                  /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x160, 5 = 64x160 */
     const void* prefetch;          /* optional: range the workgroups touch (at most 1024 128-byte lines each) */
     int64_t prefetch_bytes;        /*   so it is in the Infinity Cache for a LATER launch (next layers' weights) */
+    void* splitk_ws;               /* optional split-K workspace (iir_gemm_splitk_workspace_bytes), ZEROED once by the  */
+    int64_t splitk_ws_bytes;       /*   caller and private to one stream; lets tile = 0 pick the 2-slice form for long K  */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -60,6 +62,8 @@ typedef struct iir_gemm_desc {
 int iir_gemm_f16(const iir_gemm_desc* d, void* stream);
 /* the tile `tile = 0` resolves to for an (M, N, K) problem (paired != 0 for GEGLU / SFT epilogues) */
 int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired);
+/* bytes of split-K workspace an (M, N) problem can use (0: the split form does not apply to it) */
+int64_t iir_gemm_splitk_workspace_bytes(int32_t M, int32_t N);
 /* output-tile width BN of tile id `tile` (1..6) */
 int iir_gemm_tile_bn(int32_t tile);
 
@@ -83,6 +87,8 @@ typedef struct iir_conv_desc {
                                    /*    Downsample2D(padding=0) + F.pad(0,1,0,1), vae.py:110)      */
     const void* prefetch;          /* as in iir_gemm_desc                                          */
     int64_t prefetch_bytes;
+    void* splitk_ws;               /* as in iir_gemm_desc (M = R*Ho*Wo, N = Cout)                  */
+    int64_t splitk_ws_bytes;
 } iir_conv_desc;
 
 /* Replaces nn.Conv2d call sites: ResnetBlock2D module/min_sdxl.py:256-259,274 (+ the temb add :267 as

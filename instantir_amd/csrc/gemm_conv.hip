@@ -51,6 +51,9 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     int tiles_m, tiles_n;
     int xm, rm, rn;           // XCD partition: xm x (8/xm) rectangles of rm x rn tiles
     const char* pf; int pf_lines;   // weight prefetch: 128-byte lines to pull towards the Infinity Cache
+    int splitk;                     // 1 or 2 K slices per output tile (workgroups z = 0 / 1 of a tile share an XCD)
+    long sk_bytes;                  // host only: bytes of the caller's split-K workspace
+    float* sk_slabs; int* sk_cnt;   // split-K workspace: fp32 partial tiles [tile][z][BM*BN] and per-tile arrival counters
     int c_vec, r_vec;               // C / res rows allow 16-byte accesses (ld % 8 == 0, base 16-byte aligned)
 };
 
@@ -59,12 +62,17 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); } 
 // wait until at most N of this wave's vector-memory ops (the LDS-DMA loads) are outstanding, then barrier.
 // One asm statement with a memory clobber: no LDS access may be scheduled across it.
 template <int N>
+__device__ __forceinline__ void wait_vm_lgkm_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int N>
 __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
 template <int BM, int BN, int ST, bool CONV, int WAVES_M = 2>
-__global__ __launch_bounds__(128 * WAVES_M) void gemm_kernel(const Geo g) {
+__global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_kernel(const Geo g) {
     constexpr int NW = WAVES_M * 2, NT = 64 * NW;   // waves laid out WAVES_M x 2 over the tile
     constexpr int WM = BM / WAVES_M, WN = BN / 2;   // wave tile
     constexpr int MI = WM / 16, NI = WN / 16;    // 16x16 MFMA tiles per wave
@@ -83,9 +91,12 @@ __global__ __launch_bounds__(128 * WAVES_M) void gemm_kernel(const Geo g) {
     // cut into 8 rectangles (xm x 8/xm), one per XCD, chosen on the host to minimise the operand bytes each
     // L2 has to pull over the fabric; inside a rectangle tiles walk M fastest so co-resident workgroups
     // share a weight panel.  Placement only affects speed, never results.
+    // split-K: the grid holds every tile twice; the second half of the grid (kz = 1) works on the upper half of K.
+    // Both workgroups of a tile keep the same index mod 8, i.e. the same XCD / L2.
+    const int kz = (g.splitk == 2 && blockIdx.x >= (gridDim.x >> 1)) ? 1 : 0;
     int tm, tn;
     {
-        const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+        const int bid = kz ? (int)blockIdx.x - (int)(gridDim.x >> 1) : (int)blockIdx.x, xcd = bid & 7, local = bid >> 3;
         const int rx = xcd % g.xm, ry = xcd / g.xm;
         tm = rx * g.rm + local % g.rm;
         tn = ry * g.rn + local / g.rm;
@@ -169,34 +180,56 @@ __global__ __launch_bounds__(128 * WAVES_M) void gemm_kernel(const Geo g) {
     // ---- main loop: ST-deep LDS ring, tiles kt+1 .. kt+ST-2 stay in flight across the barrier ---------
     // (one barrier per K tile; the buffer refilled after the barrier is the one every wave finished
     //  reading before it arrived there)
-    const int nk = g.K / BK;
+    const int nk_all = g.K / BK;
+    const int kt0 = kz ? nk_all / 2 : 0, nk = g.splitk == 2 ? (kz ? nk_all : nk_all / 2) : nk_all;   // this workgroup's K tiles [kt0, nk)
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
-        if (s < nk) stage(s, s);
-    int cur = 0, nxt = ST - 1;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = nk - 1 - kt;                  // tiles issued after kt (capped at ST-2 below)
-        if (ST >= 4 && ahead >= 2) wait_vm_and_barrier<(ST >= 4 ? (ST - 2) * LOADS : 0)>();
-        else if (ST >= 3 && ahead >= 1) wait_vm_and_barrier<(ST >= 4 ? (ST - 3) * LOADS : (ST == 3 ? LOADS : 0))>();
-        else wait_vm_and_barrier<0>();
-        if (kt + ST - 1 < nk) stage(kt + ST - 1, nxt);
-        const char* as = (const char*)(As + cur * BM * BK);
-        const char* bs = (const char*)(Bs + cur * BN * BK);
+        if (kt0 + s < nk) stage(kt0 + s, s);
+
+    // Software-pipelined across the barrier: the fragments of K-step 0 of tile kt+1 are fetched from LDS while the MFMAs of
+    // K-step 1 of tile kt run, and the barrier that admits tile kt+1 sits between the two MFMA groups of tile kt -- so no
+    // LDS-read latency is exposed after a barrier (with one workgroup per CU nothing else would hide it).  The barrier
+    // also carries lgkmcnt(0): every wave's reads of tile kt are complete, so its buffer is refilled right away
+    // (tile kt+ST), one tile further ahead than a refill-then-read order allows.
+    auto frags = [&](int buf, int s, f16x8 (&af)[MI], f16x8 (&bf)[NI]) {
+        const char* as = (const char*)(As + buf * BM * BK);
+        const char* bs = (const char*)(Bs + buf * BN * BK);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 af[MI], bf[NI];
+        for (int i = 0; i < MI; ++i) af[i] = *(const f16x8*)(as + a_off[s] + i * 16 * 128);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const f16x8*)(as + a_off[s] + i * 16 * 128);
+        for (int j = 0; j < NI; ++j) bf[j] = *(const f16x8*)(bs + b_off[s] + j * 16 * 128);
+    };
+    auto mma = [&](const f16x8 (&af)[MI], const f16x8 (&bf)[NI]) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = *(const f16x8*)(bs + b_off[s] + j * 16 * 128);
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    };
+    auto admit = [&](int tiles_after) {     // wait until only `tiles_after` later tiles are still in flight, all LDS reads done, barrier
+        if (ST >= 4 && tiles_after >= 2) wait_vm_lgkm_and_barrier<(ST >= 4 ? 2 * LOADS : 0)>();
+        else if (ST >= 3 && tiles_after >= 1) wait_vm_lgkm_and_barrier<(ST >= 3 ? LOADS : 0)>();
+        else wait_vm_lgkm_and_barrier<0>();
+    };
+    f16x8 a0[MI], b0[NI], a1[MI], b1[NI];
+    {
+        const int rem = nk - 1 - kt0;
+        admit(rem < ST - 2 ? rem : ST - 2);
+        if (kt0 + ST - 1 < nk) stage(kt0 + ST - 1, ST - 1);
+        frags(0, 0, a0, b0);
+    }
+    int cur = 0;
+    for (int kt = kt0; kt < nk; ++kt) {
+        frags(cur, 1, a1, b1);
+        mma(a0, b0);
+        if (kt + 1 < nk) {
+            const int rem = nk - 2 - kt;                    // tiles that exist after kt+1
+            admit(rem < ST - 2 ? rem : ST - 2);
+            if (kt + ST < nk) stage(kt + ST, cur);          // tile kt's buffer is free: every wave finished reading it
+            cur = cur + 1 == ST ? 0 : cur + 1;
+            frags(cur, 0, a0, b0);
         }
-        cur = cur + 1 == ST ? 0 : cur + 1;
-        nxt = nxt + 1 == ST ? 0 : nxt + 1;
+        mma(a1, b1);
     }
 
     // ---- epilogue, phase 1: registers -> LDS.  A lane holds row m = ..+frow and 4 consecutive columns n = ..+4*fq+{0..3};
@@ -206,6 +239,41 @@ __global__ __launch_bounds__(128 * WAVES_M) void gemm_kernel(const Geo g) {
     // adding the residual from equally coalesced loads.  (fp16 rounding before the residual add = torch's own order:
     // the Linear / Conv output is an fp16 tensor before `+ residual`.)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading the ring
+
+    // ---- split-K: whichever of a tile's two workgroups finishes LAST adds the other's fp32 partial and runs the epilogue
+    // (a + b = b + a in fp32, so the result does not depend on which one that is).  Hand-off: all stores of the slab
+    // drained by every wave -> workgroup barrier -> one agent-scope release -> relaxed agent-scope ticket; the reducer
+    // does one agent-scope acquire, then plain loads (cdna_hip_programming.md, in-launch split-K reduction recipe).
+    if (g.splitk == 2) {
+        const int tile_id = tn * g.tiles_m + tm;
+        float* mine = g.sk_slabs + ((long)tile_id * 2 + kz) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) *(f32x4*)(mine + ((i * NI + j) * NT + tid) * 4) = acc[i][j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)(smem + ST * (BM + BN) * BK * (int)sizeof(f16));     // first word of the prefetch scratch (unused until phase 2)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(g.sk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*flag == 0) return;                                              // first to arrive: the partner finishes the tile
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            g.sk_cnt[tile_id] = 0;                                            // ready for the next launch on this stream
+        }
+        __syncthreads();
+        const float* other = g.sk_slabs + ((long)tile_id * 2 + (1 - kz)) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] += *(const f32x4*)(other + ((i * NI + j) * NT + tid) * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     const bool paired = g.epi != IIR_EPI_PLAIN;
     const int cs = (paired ? BN : 2 * BN) + 32;                          // tile row stride in bytes: odd multiple of 32 mod 256
     char* ct = smem;
@@ -366,7 +434,7 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
         cost += ((double)rm * rn * 8 - (double)g.tiles_m * g.tiles_n) * 8. * BK * (BM + BN);     // padding workgroups of ragged rectangles
         if (best < 0. || cost < best) { best = cost; g.xm = xm; g.rm = rm; g.rn = rn; }
     }
-    const dim3 grid(8 * g.rm * g.rn), block(128 * WAVES_M);
+    const dim3 grid(8 * g.rm * g.rn * (g.splitk == 2 ? 2 : 1)), block(128 * WAVES_M);
     if (conv) {
         static bool attr_c = false;
         if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
@@ -409,7 +477,26 @@ int pick_tile(int M, int N, bool paired, int K = 0) {
     return pick;
 }
 
+constexpr long SK_CNT_BYTES = 4096;     // 1024 per-tile arrival counters ahead of the slabs
+long splitk_ws_bytes(int M, int N) {
+    const long t = (long)((M + 127) / 128) * ((N + 159) / 160);
+    return t * 2 <= 256 ? SK_CNT_BYTES + t * 2 * 128 * 160 * (long)sizeof(float) : 0;
+}
+
 int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
+    // Long-K problems too small to fill the chip with 128x160 tiles (level-2 ff2, K = 5120, and 3x3 convs, K = 11520 /
+    // 23040, all M x N = 2048 x 1280): instead of one 64x160 workgroup per CU over all of K, two 128x160 workgroups per
+    // tile each take half of K -- 36 KB instead of 2 x 28 KB of operands per K tile pair, i.e. 0.64x the L2 -> LDS fill that
+    // bounds these launches -- and the last one to finish reduces (see the kernel).  Needs the caller's workspace.
+    static const bool sk_on = !(getenv("IIR_SPLITK") && atoi(getenv("IIR_SPLITK")) == 0);
+    if (tile == 0 && sk_on && g.sk_slabs && g.K >= one_per_cu_min_k() && (g.K / BK) % 2 == 0) {
+        const long need = splitk_ws_bytes(g.M, g.N);
+        if (need > 0 && g.sk_bytes >= need) {
+            Geo g2 = g;
+            g2.splitk = 2;
+            return launch<128, 160, 3>(g2, conv, stream);
+        }
+    }
     // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64, 4: 128x160, 5: 64x160}; t + 10*stages selects the ring depth.
     if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
     if (tile < 10) {
@@ -449,6 +536,8 @@ void finish_geo(Geo& g) {
 
 extern "C" int iir_gemm_tile_bn(int32_t tile) { tile %= 10; return (tile >= 1 && tile <= 6) ? kTiles[tile].bn : -1; }
 
+extern "C" int64_t iir_gemm_splitk_workspace_bytes(int32_t M, int32_t N) { return splitk_ws_bytes(M, N); }
+
 extern "C" int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired) { return pick_tile(M, N, paired != 0, K); }
 
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
@@ -467,6 +556,9 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     g.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     g.pf = (const char*)d->prefetch; g.pf_lines = d->prefetch ? (int)(d->prefetch_bytes / 128) : 0;
     finish_geo(g);
+    if (d->splitk_ws && d->splitk_ws_bytes > SK_CNT_BYTES) {
+        g.sk_cnt = (int*)d->splitk_ws; g.sk_slabs = (float*)((char*)d->splitk_ws + SK_CNT_BYTES); g.sk_bytes = d->splitk_ws_bytes;
+    }
     return dispatch(g, false, d->tile, (hipStream_t)stream);
 }
 
@@ -497,5 +589,8 @@ extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
     finish_geo(g);
     g.x_img_stride = c->x_img_stride ? c->x_img_stride : (int64_t)c->H * c->Wd * c->ldx;
     g.y_img_rows = c->y_img_rows; g.res_img_rows = c->res_img_rows;
+    if (c->splitk_ws && c->splitk_ws_bytes > SK_CNT_BYTES) {
+        g.sk_cnt = (int*)c->splitk_ws; g.sk_slabs = (float*)((char*)c->splitk_ws + SK_CNT_BYTES); g.sk_bytes = c->splitk_ws_bytes;
+    }
     return dispatch(g, true, c->tile, (hipStream_t)stream);
 }

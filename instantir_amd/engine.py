@@ -136,6 +136,7 @@ class _Net:
         self._pf_stream = None
         self._pf_forked = False
         self._gnws = None
+        self._skws = None
         self._warena = None
         self.inkernel_prefetch = True
         self._pack_encoder(sd)
@@ -242,6 +243,8 @@ class _Net:
         plain = self.w
         first = not self.units
         self._gnws = ops.gn_workspace(self.device, 64, self.cfg.norm_groups)
+        if self._skws is None:     # split-K workspace (zeroed once; this network's launches share one stream order)
+            self._skws = torch.zeros(4096 + 256 * 128 * 160 * 4, dtype=torch.uint8, device=self.device)
         if first:
             self._use_log = []
             self.w = _RecDict(plain, lambda k: self._use_log.append(k))
@@ -351,7 +354,8 @@ class _Net:
         o.groupnorm(x, h, R, HW, w[path + ".norm1.g"], w[path + ".norm1.b"], eps, True, self.cfg.norm_groups, self._gnws)
         h2 = A.alloc(R * HW, cout)
         o.conv2d(h.view(R, H, W, cin), w[path + ".conv1.w"], h2, bias=w[path + ".conv1.b"],
-                 rowbias=temb_all[:, self._temb_slices[path]], rows_per_rb=HW, prefetch=self._pf(w[path + ".conv1.w"]))
+                 rowbias=temb_all[:, self._temb_slices[path]], rows_per_rb=HW, prefetch=self._pf(w[path + ".conv1.w"]),
+                 splitk_ws=self._skws)
         h3 = A.alloc(R * HW, cout)
         o.groupnorm(h2, h3, R, HW, w[path + ".norm2.g"], w[path + ".norm2.b"], eps, True, self.cfg.norm_groups, self._gnws)
         if (path + ".conv_shortcut.w") in w:
@@ -360,7 +364,7 @@ class _Net:
         else:
             sc = x
         o.conv2d(h3.view(R, H, W, cout), w[path + ".conv2.w"], out, bias=w[path + ".conv2.b"], res=sc,
-                 prefetch=self._pf(w[path + ".conv2.w"]))
+                 prefetch=self._pf(w[path + ".conv2.w"]), splitk_ws=self._skws)
         A.release(m)
         return out
 
@@ -399,7 +403,7 @@ class _Net:
         o.layernorm(h, n, w[p + ".norm3.g"], w[p + ".norm3.b"], 1e-5)
         f = A.alloc(M, 4 * C)
         o.gemm(n, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.w"]))
-        o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]))
+        o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]), splitk_ws=self._skws)
         A.release(m)
 
     def _transformer(self, path, x, depth, R, H, W, st, ada, out=None):

@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("out_scale", C.c_float),
         ("tile", C.c_int32),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -50,6 +51,7 @@ class ConvDesc(C.Structure):
         ("zero_page", C.c_void_p),
         ("x_img_stride", C.c_int64), ("y_img_rows", C.c_int32), ("res_img_rows", C.c_int32), ("pad_mode", C.c_int32),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -84,6 +86,7 @@ _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # symbol -> (restype, argtypes); must list every function declared in include/instantir_hip.h
 SIGNATURES = {
     "iir_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "iir_gemm_splitk_workspace_bytes": (C.c_int64, [_I32, _I32]),
     "iir_gemm_pick_tile": (C.c_int, [_I32, _I32, _I32, _I32]),
     "iir_gemm_tile_bn": (C.c_int, [_I32]),
     "iir_conv2d_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), _P]),

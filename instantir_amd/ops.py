@@ -97,8 +97,14 @@ def zero_page(device):
     return z
 
 
+def splitk_workspace(M, N, device):
+    """Zeroed split-K workspace for (M, N) problems (None when the 2-slice form does not apply).  One per stream."""
+    n = L.load().iir_gemm_splitk_workspace_bytes(M, N)
+    return torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
 def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
-         tile=0, prefetch=None):
+         tile=0, prefetch=None, splitk_ws=None):
     """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues)."""
     _chk2d(a, "a"); _chk2d(w, "w"); _chk2d(out, "out")
     M, K = a.shape
@@ -125,6 +131,8 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
+    if splitk_ws is not None:
+        d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
     No = N // 2 if epi != EPI_PLAIN else N
     with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile % 10], 2.0 * M * N * K,
                 2.0 * (M * K + N * K + M * No + (M * No if res is not None else 0))):
@@ -133,7 +141,8 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
 
 
 def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None, rows_per_rb=1, res=None,
-           epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0, tile=0, y_img_rows=0, res_img_rows=0, pad_mode=0, prefetch=None):
+           epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0, tile=0, y_img_rows=0, res_img_rows=0, pad_mode=0, prefetch=None,
+           splitk_ws=None):
     """x (R,H,W,Cin) NHWC view (pixel stride x.stride(2), image stride x.stride(0) free), w (Cout,k,k,Cin) contiguous,
     out (rows, Cout[/2]) 2-D view; image i's pixels start at row i*y_img_rows (0 = dense)."""
     R, H, Wd, Cin = x.shape
@@ -165,6 +174,8 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     d.zero_page = zero_page(x.device).data_ptr()
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
+    if splitk_ws is not None:
+        d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
     d.x_img_stride, d.y_img_rows, d.res_img_rows, d.pad_mode = x.stride(0), y_img_rows, res_img_rows, pad_mode
     Co = Cout // 2 if epi != EPI_PLAIN else Cout
     with _Timed("gemm_kernel<%s,conv>" % _TILE_NAMES[tile % 10], 2.0 * Mo * Cout * ksize * ksize * Cin,

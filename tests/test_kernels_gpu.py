@@ -46,6 +46,58 @@ def test_gemm_plain(dev, tile, M, N, K):
     assert out[:, N:].abs().max().item() == 0          # nothing written outside the view
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(2048, 1280, 5120, False), (300, 320, 2560, False), (512, 640, 2688, True), (32, 256, 4608, False)])
+def test_gemm_split_k(dev, M, N, K, geglu):
+    """Two-slice split-K (tile = 0 with a workspace on long-K, few-tile problems): the last of a tile's two workgroups
+    reduces.  Same result as the unsplit launch up to fp32 summation order, identical across repeated launches
+    (the arrival order must not matter), counters left zeroed."""
+    from instantir_amd import ops
+    from instantir_amd.packing import pair_rows
+    g = torch.Generator().manual_seed(M + K)
+    a, w, bias, res = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N), _rand(g, M, N // 2 if geglu else N)
+    ws = ops.splitk_workspace(M, N, dev)
+    assert ws is not None and ws.numel() == 4096 + ((M + 127) // 128) * ((N + 159) // 160) * 2 * 128 * 160 * 4
+    ad = a.to(dev)
+    if geglu:
+        h = a.float() @ w.float().T + bias.float()
+        want = h[:, :N // 2] * F.gelu(h[:, N // 2:])
+        wd, bd = pair_rows(w[:N // 2], w[N // 2:]).to(dev), pair_rows(bias[:N // 2], bias[N // 2:]).to(dev)
+        kw = dict(bias=bd, epi=ops.EPI_GEGLU)
+    else:
+        want = a.float() @ w.float().T + bias.float() + res.float()
+        wd = w.to(dev)
+        kw = dict(bias=bias.to(dev), res=res.to(dev))
+    No = want.shape[1]
+    plain = torch.empty(M, No, dtype=torch.half, device=dev)
+    ops.gemm(ad, wd, plain, **kw)
+    outs = []
+    for _ in range(3):
+        o = torch.zeros(M, No, dtype=torch.half, device=dev)
+        ops.gemm(ad, wd, o, splitk_ws=ws, **kw)
+        outs.append(o)
+    torch.cuda.synchronize()
+    _close(outs[0], want, what="split-K gemm")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert (outs[0].float() - plain.float()).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+    assert ws[:4096].view(torch.int32).abs().max().item() == 0
+
+
+def test_conv_split_k(dev):
+    from instantir_amd import ops
+    from instantir_amd.packing import conv_weight_nhwc
+    g = torch.Generator().manual_seed(5)
+    R, H, W, Cin, Cout = 2, 16, 16, 320, 320                  # K = 2880 = 45 K tiles: odd -> falls back to the unsplit form
+    for Cin in (320, 384):                                       # 384: K = 3456 = 54 tiles -> split
+        x, w, b = _rand(g, R, Cin, H, W), _rand(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5), _rand(g, Cout)
+        want = _nhwc(F.conv2d(x.float(), w.float(), b.float(), padding=1)).reshape(R * H * W, Cout)
+        ws = ops.splitk_workspace(R * H * W, Cout, dev)
+        out = torch.empty(R * H * W, Cout, dtype=torch.half, device=dev)
+        ops.conv2d(_nhwc(x).to(dev), conv_weight_nhwc(w).to(dev), out, ksize=3, bias=b.to(dev), splitk_ws=ws)
+        torch.cuda.synchronize()
+        _close(out, want, what=f"split-K conv Cin={Cin}")
+        assert ws[:4096].view(torch.int32).abs().max().item() == 0
+
+
 def test_gemm_strided_a_and_scale(dev):
     from instantir_amd import ops
     g = torch.Generator().manual_seed(3)
