@@ -54,6 +54,7 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     int splitk;                     // 1 or 2 K slices per output tile (workgroups z = 0 / 1 of a tile share an XCD)
     long sk_bytes;                  // host only: bytes of the caller's split-K workspace
     float* sk_slabs; int* sk_cnt;   // split-K workspace: fp32 partial tiles [tile][z][BM*BN] and per-tile arrival counters
+    f16* Ct; long ldct; int tr_from, ct_vec;   // columns n >= tr_from are stored transposed: Ct[(n - tr_from) * ldct + m]
     int c_vec, r_vec;               // C / res rows allow 16-byte accesses (ld % 8 == 0, base 16-byte aligned)
 };
 
@@ -348,7 +349,27 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
         const bool use_res = g.res && !paired;
         const bool remap = CONV && (g.y_img_rows | g.res_img_rows);
         // whole tile inside the matrix, rows 16-byte addressable: straight-line code, no predicates on the loads
-        const bool fast = g.c_vec && (!use_res || g.r_vec) && m0 + BM <= g.M && no_tile + CPR * 8 <= No && !remap;
+        const bool tr_tile = g.Ct && no_tile >= g.tr_from;                 // this whole tile lies in the transposed column range
+        const bool tr_mixed = g.Ct && !tr_tile && no_tile + CPR * 8 > g.tr_from;
+        const bool inside = m0 + BM <= g.M && no_tile + CPR * 8 <= No && !remap;
+        const bool fast = !tr_tile && !tr_mixed && g.c_vec && (!use_res || g.r_vec) && inside;
+        if (tr_tile && inside && g.ct_vec && !use_res) {
+            // transposed write-out (the V third of a fused q|k|v projection becomes the V^T image the attention kernel reads):
+            // a lane gathers 8 consecutive rows of one tile column from LDS and stores them as 16 contiguous bytes of Ct.
+            constexpr int RC = BM / 8, TOTAL_T = (CPR * 8) * RC, CH_T = (TOTAL_T + NT - 1) / NT;
+            touch_next_weights();
+#pragma unroll
+            for (int k = 0; k < CH_T; ++k) {
+                const int idx = tid + k * NT;
+                if (TOTAL_T % NT != 0 && idx >= TOTAL_T) break;
+                const int c = idx / RC, rc = idx - c * RC;
+                f16x8 o;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o[t] = (f16)((float)*(const f16*)(ct + (rc * 8 + t) * cs + c * 2) * g.out_scale);
+                *(f16x8*)(g.Ct + (long)(no_tile + c - g.tr_from) * g.ldct + m0 + rc * 8) = o;
+            }
+            return;
+        }
         // (hipcc drains every LDS-DMA in flight at the next use of an ordinary load's result, so the touches are issued
         //  after the residuals have been consumed and ahead of the stores, which need no wait)
         if (fast) {
@@ -399,6 +420,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
 #pragma unroll 1
                 for (int t = 0; t < 8 && n + t < No; ++t) {
                     float v = (float)tp[t];
+                    if (g.Ct && n + t >= g.tr_from) { g.Ct[(long)(n + t - g.tr_from) * g.ldct + mc] = (f16)(v * g.out_scale); continue; }
                     if (use_res) v += (float)g.res[mr * g.ldr + n + t];
                     g.C[mc * g.ldc + n + t] = (f16)(v * g.out_scale);
                 }
@@ -556,6 +578,11 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     g.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     g.pf = (const char*)d->prefetch; g.pf_lines = d->prefetch ? (int)(d->prefetch_bytes / 128) : 0;
     finish_geo(g);
+    if (d->Ct) {
+        if (d->epi != IIR_EPI_PLAIN || d->tr_from < 0 || d->tr_from >= d->N || d->tr_from % 8 || d->ldct < d->M) return IIR_EINVAL;
+        g.Ct = (f16*)d->Ct; g.ldct = d->ldct; g.tr_from = d->tr_from;
+        g.ct_vec = (d->ldct % 8 == 0) && ((uintptr_t)d->Ct % 16 == 0);
+    }
     if (d->splitk_ws && d->splitk_ws_bytes > SK_CNT_BYTES) {
         g.sk_cnt = (int*)d->splitk_ws; g.sk_slabs = (float*)((char*)d->splitk_ws + SK_CNT_BYTES); g.sk_bytes = d->splitk_ws_bytes;
     }

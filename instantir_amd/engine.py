@@ -28,6 +28,8 @@ MI355X-first restructuring (observable results unchanged):
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
@@ -139,6 +141,7 @@ class _Net:
         self._skws = None
         self._warena = None
         self.inkernel_prefetch = True
+        self.fuse_qkv = os.environ.get("IIR_FUSE_QKV", "1") != "0"
         self._pack_encoder(sd)
 
     # ---- weight packing ---------------------------------------------------------------------
@@ -177,8 +180,9 @@ class _Net:
         for k in range(depth):
             p = f"{path}.transformer_blocks.{k}"
             self._pack_norm(sd, p + ".norm1")
-            self.w[p + ".attn1.qk.w"] = torch.cat([self._t(sd, p + ".attn1.to_q.weight"), self._t(sd, p + ".attn1.to_k.weight")], 0).contiguous()
-            self.w[p + ".attn1.v.w"] = self._t(sd, p + ".attn1.to_v.weight").contiguous()
+            # one projection for q | k | v: the V third is written transposed by the GEMM's epilogue (iir_gemm_desc.Ct)
+            self.w[p + ".attn1.qkv.w"] = torch.cat([self._t(sd, p + ".attn1.to_q.weight"), self._t(sd, p + ".attn1.to_k.weight"),
+                                                    self._t(sd, p + ".attn1.to_v.weight")], 0).contiguous()
             self._pack_linear(sd, p + ".attn1.to_out.0")
             if self.cross:
                 self._pack_norm(sd, p + ".norm2")
@@ -379,9 +383,13 @@ class _Net:
         # -- self-attention (AttnProcessor2_0, attention_processor.py:370-402)
         o.layernorm(h, n, w[p + ".norm1.g"], w[p + ".norm1.b"], 1e-5)
         qk = A.alloc(M, 2 * C)
-        o.gemm(n, w[p + ".attn1.qk.w"], qk, prefetch=self._pf(w[p + ".attn1.qk.w"]))
         vt = A.alloc(C, M)
-        o.gemm(w[p + ".attn1.v.w"], n, vt, prefetch=self._pf(w[p + ".attn1.v.w"]))     # V^T = Wv . X^T
+        wqkv = w[p + ".attn1.qkv.w"]
+        if self.fuse_qkv:
+            o.gemm(n, wqkv, qk, prefetch=self._pf(wqkv), out_t=(vt, 2 * C))             # q | k, and V^T from the same launch
+        else:
+            o.gemm(n, wqkv[:2 * C], qk, prefetch=self._pf(wqkv))
+            o.gemm(wqkv[2 * C:], n, vt)                                                   # V^T = Wv . X^T (operands swapped)
         a = A.alloc(M, C)
         o.attention(qk[:, :C], a, [(qk[:, C:], T, vt, T, T)], R, heads, T)
         o.gemm(a, w[p + ".attn1.to_out.0.w"], h, bias=w[p + ".attn1.to_out.0.b"], res=h,

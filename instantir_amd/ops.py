@@ -104,14 +104,15 @@ def splitk_workspace(M, N, device):
 
 
 def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
-         tile=0, prefetch=None, splitk_ws=None):
-    """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues)."""
+         tile=0, prefetch=None, splitk_ws=None, out_t=None):
+    """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues).
+    out_t = (Ct, tr_from): output columns >= tr_from go, transposed, to Ct[n - tr_from, m]; `out` then is (M, tr_from)."""
     _chk2d(a, "a"); _chk2d(w, "w"); _chk2d(out, "out")
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K or not w.is_contiguous():
         raise ValueError("w must be contiguous (N,K) with K matching a")
-    n_out = N if epi == EPI_PLAIN else N // 2
+    n_out = (N if epi == EPI_PLAIN else N // 2) if out_t is None else out_t[1]
     if out.shape != (M, n_out):
         raise ValueError(f"out shape {tuple(out.shape)} != {(M, n_out)}")
     d = L.GemmDesc()
@@ -133,6 +134,12 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
         d.prefetch, d.prefetch_bytes = prefetch
     if splitk_ws is not None:
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
+    if out_t is not None:
+        ct, tr_from = out_t
+        _chk2d(ct, "out_t")
+        if ct.shape[0] < N - tr_from or ct.shape[1] < M:
+            raise ValueError("out_t must hold (N - tr_from, M)")
+        d.Ct, d.ldct, d.tr_from = ct.data_ptr(), ct.stride(0), tr_from
     No = N // 2 if epi != EPI_PLAIN else N
     with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile % 10], 2.0 * M * N * K,
                 2.0 * (M * K + N * K + M * No + (M * No if res is not None else 0))):

@@ -98,6 +98,24 @@ def test_conv_split_k(dev):
         assert ws[:4096].view(torch.int32).abs().max().item() == 0
 
 
+@pytest.mark.parametrize("M,C,tile", [(256, 160, 0), (2048, 640, 0), (200, 128, 0), (512, 128, 2), (96, 64, 3), (1024, 320, 4)])
+def test_gemm_transposed_column_range(dev, M, C, tile):
+    """Fused q|k|v projection: columns [0, 2C) row-major, columns [2C, 3C) stored transposed (iir_gemm_desc.Ct) -- whole
+    transposed tiles, tiles straddling tr_from and ragged M all give the two plain products."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    K = 128
+    a, w, bias = _rand(g, M, K), _rand(g, 3 * C, K, scale=K ** -0.5), _rand(g, 3 * C)
+    want = a.float() @ w.float().T + bias.float()
+    qk = torch.zeros(M, 2 * C + 8, dtype=torch.half, device=dev)
+    vt = torch.zeros(C, M + 8, dtype=torch.half, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), qk[:, :2 * C], bias=bias.to(dev), out_t=(vt[:, :M], 2 * C), tile=tile)
+    torch.cuda.synchronize()
+    _close(qk[:, :2 * C], want[:, :2 * C], what="q|k part")
+    _close(vt[:, :M], want[:, 2 * C:].T, what="V^T part")
+    assert qk[:, 2 * C:].abs().max().item() == 0 and vt[:, M:].abs().max().item() == 0
+
+
 def test_gemm_strided_a_and_scale(dev):
     from instantir_amd import ops
     g = torch.Generator().manual_seed(3)
