@@ -186,8 +186,12 @@ class HipCLIPText:
         self.proj = sd["text_projection.weight"].to(dev, F16).contiguous() if "text_projection.weight" in sd else None
 
     @torch.no_grad()
-    def forward(self, input_ids: torch.Tensor):
-        """input_ids (B, T<=77) int64.  Returns (hidden_states[-2] (B, T, D) fp16, text_embeds (B, P) fp16 or None)."""
+    def forward(self, input_ids: torch.Tensor, clip_skip=None):
+        """input_ids (B, T<=77) int64.  Returns (hidden_states[-2] (B, T, D) fp16 -- hidden_states[-(clip_skip + 2)] when
+        `clip_skip` is given, pipelines/sdxl_instantir.py:524-530 -- and text_embeds (B, P) fp16 or None)."""
+        take = self.depth - 1 - (clip_skip or 0)            # the kept state is the INPUT of layer `take`
+        if not 0 <= take < self.depth:
+            raise ValueError(f"clip_skip={clip_skip} out of range for a {self.depth}-layer text encoder")
         dev, D, w = self.device, self.D, self.w
         ids = input_ids.to(dev)
         B, T = ids.shape
@@ -206,7 +210,7 @@ class HipCLIPText:
         f = torch.empty(M, w["0.fc1.w"].shape[0], dtype=F16, device=dev)
         penult = None
         for i in range(self.depth):
-            if i == self.depth - 1:
+            if i == take:
                 penult = h.clone()                                        # hidden_states[-2]: input of the last layer
             ops.layernorm(h, n, w[f"{i}.n1.g"], w[f"{i}.n1.b"], self.eps)
             ops.gemm(n, w[f"{i}.qk.w"], qk, bias=w[f"{i}.qk.b"])
@@ -234,9 +238,9 @@ class HipCLIPText:
     __call__ = forward
 
 
-def encode_prompt_ids(enc1: HipCLIPText, enc2: HipCLIPText, ids1: torch.Tensor, ids2: torch.Tensor):
+def encode_prompt_ids(enc1: HipCLIPText, enc2: HipCLIPText, ids1: torch.Tensor, ids2: torch.Tensor, clip_skip=None):
     """The tensor part of `encode_prompt` (pipelines/sdxl_instantir.py:516-560): concat the two penultimate hidden
     states -> (B, 77, 2048) prompt_embeds; pooled = projected EOS feature of the second encoder -> (B, 1280)."""
-    h1, _ = enc1(ids1)
-    h2, pooled = enc2(ids2)
+    h1, _ = enc1(ids1, clip_skip)
+    h2, pooled = enc2(ids2, clip_skip)
     return torch.cat([h1, h2], dim=-1), pooled

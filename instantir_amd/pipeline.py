@@ -217,7 +217,7 @@ class InstantIRPipeline:
                                  f"{ip_adapter_image_embeds[0].ndim}D")
 
     def encode_prompt(self, prompt=None, prompt_2=None, negative_prompt=None, negative_prompt_2=None, prompt_ids=None,
-                      prompt_ids_2=None, negative_prompt_ids=None, negative_prompt_ids_2=None, do_cfg=True):
+                      prompt_ids_2=None, negative_prompt_ids=None, negative_prompt_ids_2=None, do_cfg=True, clip_skip=None):
         """`encode_prompt` (pipelines/sdxl_instantir.py:400-632) on the HIP text encoders: both CLIP encoders'
         hidden_states[-2] concatenated (B,77,2048) + the second encoder's projected EOS feature (B,1280).  Strings
         go through the attached tokenizers (77 tokens, padded / truncated); ids may be passed directly.  With no
@@ -233,7 +233,7 @@ class InstantIRPipeline:
             prompt_ids_2 = ids_of(prompt_2 if prompt_2 is not None else prompt, self.tokenizer_2 or self.tokenizer)
         if prompt_ids_2 is None:
             prompt_ids_2 = prompt_ids
-        pe, pooled = encode_prompt_ids(self.text_encoder, self.text_encoder_2, prompt_ids, prompt_ids_2)
+        pe, pooled = encode_prompt_ids(self.text_encoder, self.text_encoder_2, prompt_ids, prompt_ids_2, clip_skip)
         npe = npooled = None
         if do_cfg:
             if negative_prompt_ids is None and negative_prompt is not None:
@@ -243,6 +243,7 @@ class InstantIRPipeline:
             if negative_prompt_ids is None:
                 npe, npooled = torch.zeros_like(pe), torch.zeros_like(pooled)
             else:
+                # (the reference always takes hidden_states[-2] for the negative prompt, :586: clip_skip is not applied)
                 npe, npooled = encode_prompt_ids(self.text_encoder, self.text_encoder_2, negative_prompt_ids,
                                                  negative_prompt_ids_2 if negative_prompt_ids_2 is not None else negative_prompt_ids)
         return pe, npe, pooled, npooled
@@ -343,6 +344,9 @@ class InstantIRPipeline:
         bit-reproducible parity runs: `init_noise` (the randn of init_latents) and
         `step_noises` (list of per-step DDPM noises) replace draws from `generator` when given.
         `image` must be the LQ *latent* (B,4,h,w) here unless a VAE is attached (`image.shape[1] == 4` branch of :1369-1382)."""
+        if cross_attention_kwargs:
+            raise NotImplementedError("cross_attention_kwargs are not forwarded: the attention processors are fixed kernels "
+                                      "(the LoRA scale is folded into the previewer weight copy at prepare_previewers)")
         if multistep_restore:
             raise NotImplementedError("multistep_restore passes kwargs the shipped DDPM scheduler does not accept "
                                       "(SURVEY.md Appendix C Q5)")
@@ -362,7 +366,7 @@ class InstantIRPipeline:
         if prompt_embeds is None:                                                   # :1325-1348
             prompt_embeds, ne, pooled_prompt_embeds, npool = self.encode_prompt(
                 prompt, prompt_2, negative_prompt, negative_prompt_2, kwargs.get("prompt_ids"), kwargs.get("prompt_ids_2"),
-                kwargs.get("negative_prompt_ids"), kwargs.get("negative_prompt_ids_2"), do_cfg)
+                kwargs.get("negative_prompt_ids"), kwargs.get("negative_prompt_ids_2"), do_cfg, clip_skip)
             if negative_prompt_embeds is None:
                 negative_prompt_embeds, negative_pooled_prompt_embeds = ne, npool
         B = prompt_embeds.shape[0] * num_images_per_prompt
@@ -397,7 +401,15 @@ class InstantIRPipeline:
         if cfg.addition_time_embed_dim * len(ids) + cfg.pooled_dim != cfg.add_embed_in:
             raise ValueError("Model expects an added time embedding vector of length "
                              f"{cfg.add_embed_in}, but a vector of {cfg.addition_time_embed_dim * len(ids) + cfg.pooled_dim} was created.")
-        time_ids = torch.tensor([ids], dtype=torch.float32).repeat(R, 1)
+        neg_ids = ids
+        if negative_original_size is not None and negative_target_size is not None:   # :1445-1454
+            neg_ids = list(negative_original_size) + list(negative_crops_coords_top_left) + list(negative_target_size)
+        if do_cfg:
+            # :1459,:1464 verbatim: cat([neg, pos]) then .repeat(B, 1) -- for B > 1 the rows alternate neg, pos, neg, ... while
+            # the prompt rows are [neg x B; pos x B]; only observable when negative sizes differ from the positive ones
+            time_ids = torch.tensor([neg_ids, ids], dtype=torch.float32).repeat(B, 1)
+        else:
+            time_ids = torch.tensor([ids], dtype=torch.float32).repeat(R, 1)
         if ip_adapter_image_embeds is None:                                         # :1350-1357
             if ip_adapter_image is None:
                 raise ValueError("InstantIR conditions on the LQ image: pass `ip_adapter_image` or `ip_adapter_image_embeds`")

@@ -14,7 +14,7 @@ def denoise(P, PA, lora, cfg, lq, prompt_embeds, pooled, image_embeds, *, negati
             negative_pooled=None, num_inference_steps=30, guidance_scale=7.0, sampler="ddim", eta=0.0,
             init_noise=None, step_noises=None, controlnet_conditioning_scale=1.0, control_guidance_start=0.0,
             control_guidance_end=1.0, preview_start=0.0, preview_end=1.0, use_previewer=True, trace=None,
-            guidance_rescale=0.0):
+            guidance_rescale=0.0, negative_time_ids=None):
     """Returns the final latents (B,4,h,w).  `lq`: LQ latent (B,4,h,w); `image_embeds`: (2,B,S,E) [neg;pos] under CFG
     (pipelines/sdxl_instantir.py:700-707) else (1,B,S,E).  `trace` (dict) collects per-step tensors when given."""
     B = lq.shape[0]
@@ -34,7 +34,10 @@ def denoise(P, PA, lora, cfg, lq, prompt_embeds, pooled, image_embeds, *, negati
     else:
         ctx, text_embeds, image = prompt_embeds, pooled, lq
     R = ctx.shape[0]
-    tid = tid.repeat(R, 1)
+    if do_cfg and negative_time_ids is not None:                           # :1445-1464: cat([neg, pos]).repeat(B, 1), row order as is
+        tid = torch.cat([torch.tensor([list(negative_time_ids)], dtype=torch.float32), tid]).repeat(B, 1)
+    else:
+        tid = tid.repeat(R, 1)
     ip_main = nets.image_projection(P, [image_embeds], cfg.resampler)[0]
     ip_prev = nets.image_projection(P, [image_embeds], cfg.resampler, lora)[0] if lora is not None else None
     x = sched.add_noise(acp, lq, init_noise, [int(ts[0])] * B)               # :1389, :931-939

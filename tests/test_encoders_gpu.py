@@ -93,6 +93,10 @@ def test_clip_text_matches_transformers(act, eos):
     assert h.shape == (2, 77, 128) and pooled.shape == (2, 96)
     assert psnr(h.float().cpu(), out.hidden_states[-2]) > 45
     assert psnr(pooled.float().cpu(), out.text_embeds) > 40
+    h1, pooled1 = enc(ids, clip_skip=1)                         # hidden_states[-(clip_skip + 2)], pooled unchanged (:524-530)
+    assert psnr(h1.float().cpu(), out.hidden_states[-3]) > 45 and torch.equal(pooled1, pooled)
+    with pytest.raises(ValueError):
+        enc(ids, clip_skip=3)
 
 
 def test_pipeline_with_encoders_attached():

@@ -107,6 +107,20 @@ def test_guidance_rescale_loop(env):
     assert psnr(got, plain) < p - 6          # the rescale is live: clearly closer to the rescaled oracle than to the plain one
 
 
+def test_negative_size_conditioning(env):
+    """negative_original_size / negative_target_size (pipelines/sdxl_instantir.py:1445-1464) reach the uncond rows' time ids."""
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    kw = dict(num_inference_steps=2, guidance_scale=5.0)
+    neg = (64, 96, 8, 4, 32, 48)
+    want = _oracle(cfg, sd, sda, lora, inp, sampler="ddim", negative_time_ids=neg, **kw)
+    plain = _oracle(cfg, sd, sda, lora, inp, sampler="ddim", **kw)
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    got = _call(pipe, inp, negative_original_size=neg[:2], negative_crops_coords_top_left=neg[2:4], negative_target_size=neg[4:], **kw)
+    p = psnr(got, want)
+    assert p >= 40 and psnr(got, plain) < p - 6, (p, psnr(got, plain))
+
+
 def test_no_cfg_single_image(env):
     """BASELINE config 1 shape of the control flow: cfg = 1.0 (no CFG doubling), 4 steps."""
     from instantir_amd.schedulers import DDIMScheduler
