@@ -55,6 +55,25 @@ class _AggregatorHandle:
     def to(self, *a, **k):
         return self
 
+    def from_unet(self):
+        """`Aggregator.from_unet(unet)` + `remove_attn2` (module/aggregator.py:503-578, pipelines/sdxl_instantir.py:165-177,
+        320-322) -- what the reference pipeline holds when no aggregator is passed in: `conv_in` (also as `ref_conv_in`),
+        time / add embeddings, down blocks and mid block copied from the UNet (cross-attention and its norm dropped), the
+        SFT heads freshly initialised behind zero 1x1 convolutions, so every residual it emits is exactly zero.  (The
+        reference draws the SFT 3x3 weights from PyTorch's default init; behind the zero convs their values are unobservable,
+        zeros are used.)"""
+        from .weights import aggregator_specs
+        usd = self._pipe._unet_sd
+        out = {}
+        for name, shape, _ in aggregator_specs(self._pipe.cfg):
+            if name.startswith("ref_conv_in."):
+                out[name] = usd["conv_in." + name[len("ref_conv_in."):]]
+            elif name.startswith("controlnet_"):
+                out[name] = torch.zeros(shape, dtype=torch.float32)
+            else:
+                out[name] = usd[name]
+        return out
+
 
 class InstantIRPipeline:
     vae_scale_factor = 8
@@ -171,7 +190,7 @@ class InstantIRPipeline:
             self._unet_prev = HipUNet(self.cfg, self._unet_sd, self.device, lora=self._lora, lora_scaling=self._lora_scaling)
         if self._agg is None:
             if self._agg_sd is None:
-                raise RuntimeError("aggregator weights not loaded: call pipe.aggregator.load_state_dict(...)")
+                self._agg_sd = self.aggregator.from_unet()
             self._agg = HipAggregator(self.cfg, self._agg_sd, self.device)
 
     # ---- input checks (pipelines/sdxl_instantir.py:749-864, the conditions that apply to tensor inputs) ----

@@ -121,6 +121,24 @@ def test_negative_size_conditioning(env):
     assert p >= 40 and psnr(got, plain) < p - 6, (p, psnr(got, plain))
 
 
+def test_aggregator_from_unet_emits_zero_residuals(env):
+    """No aggregator weights loaded: the pipeline builds Aggregator.from_unet (module/aggregator.py:503-578) -- UNet encoder
+    weights, SFT heads behind zero convolutions -- so every residual is zero; checked against the oracle given that state dict."""
+    from instantir_amd.pipeline import InstantIRPipeline
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    bare = InstantIRPipeline(cfg, sd, scheduler=DDIMScheduler())
+    bare.prepare_previewers(lora, lora_alpha=16)
+    agg = bare.aggregator.from_unet()
+    assert set(agg) == set(sda) and all(agg[k].abs().max().item() == 0 for k in agg if k.startswith("controlnet_"))
+    assert torch.equal(agg["ref_conv_in.weight"], sd["conv_in.weight"]) and torch.equal(agg["mid_block.resnets.0.conv1.weight"], sd["mid_block.resnets.0.conv1.weight"])
+    got = _call(bare, inp, num_inference_steps=2, guidance_scale=5.0)
+    want = _oracle(cfg, sd, agg, lora, inp, num_inference_steps=2, guidance_scale=5.0, sampler="ddim")
+    trained = _oracle(cfg, sd, sda, lora, inp, num_inference_steps=2, guidance_scale=5.0, sampler="ddim")
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p >= 40 and psnr(got, trained) < p - 6
+
+
 def test_no_cfg_single_image(env):
     """BASELINE config 1 shape of the control flow: cfg = 1.0 (no CFG doubling), 4 steps."""
     from instantir_amd.schedulers import DDIMScheduler
