@@ -11,11 +11,12 @@
 //          is gathered straight from the input image (zero page for padding) -- no im2col buffer.
 //          W is [Cout][ks][ks][Cin].  stride 1/2; `ups` folds a nearest-2x upsample into the gather.
 //
-// Structure (v1): BMxBNx64 block tile, 4 waves (2x2), operands staged by global_load_lds_dwordx4
-// into a double-buffered, XOR-swizzled LDS image (swizzle applied on the per-lane SOURCE address so
-// the LDS write stays lane-linear), fragments by ds_read_b128, XCD-aware tile order.
-// The weight fragment is the MFMA "A" operand so each lane ends up with 4 consecutive output
-// columns of one row -> 8-byte packed stores and 8-byte bias/residual loads in the epilogue.
+// Structure: BMxBNx64 block tile, 4 waves (2x2; 8 for the 256x128 tile), operands staged by global_load_lds_dwordx4
+// into an ST-deep ring of XOR-swizzled LDS images (swizzle applied on the per-lane SOURCE address so the LDS write
+// stays lane-linear), fragments by ds_read_b128 double-buffered across the barrier, XCD-aware tile order.
+// The weight fragment is the MFMA "A" operand so each lane ends up with 4 consecutive output columns of one row;
+// the finished tile is staged through the (then idle) ring and written out in whole rows (or, for a column range,
+// transposed).  Optional: two-slice split-K with an in-launch reduction, LayerNorm of the A rows folded in.
 #include "common.h"
 #include "../../include/instantir_hip.h"
 #include <stdlib.h>
