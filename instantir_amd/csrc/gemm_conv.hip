@@ -140,6 +140,39 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
         b_src[i] = g.W + (long)n * g.K + schunk * 8;
     }
 
+    // conv gather state: stage() is called for consecutive K tiles, so the (tap, channel) walk is incremental -- per tile one
+    // pointer bump per row group; the pixel / padding arithmetic runs only when the tap changes (every Cin/64 tiles).  It
+    // used to be redone for every tile: ~40 VALU instructions beside 40 MFMAs.
+    const f16* cv_ptr[CONV ? A_INST : 1];
+    int cv_inc[CONV ? A_INST : 1];
+    int cv_c0 = 0, cv_tap = 0;
+    auto conv_tap = [&](int tap) {
+        const int ky = tap / g.ks, kx = tap - ky * g.ks;
+#pragma unroll
+        for (int i = 0; i < (CONV ? A_INST : 0); ++i) {
+            const int iy = a_pix_y[i] + ky, ix = a_pix_x[i] + kx;
+            bool ok;
+            long pix;
+            if (g.ups) {   // coordinates are in the 2x-upsampled domain
+                ok = (iy >= 0) & (iy < 2 * g.H) & (ix >= 0) & (ix < 2 * g.Wd);
+                pix = (long)(iy >> 1) * g.Wd + (ix >> 1);
+            } else {
+                ok = (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.Wd);
+                pix = (long)iy * g.Wd + ix;
+            }
+            cv_ptr[i] = ok ? a_img[i] + pix * g.lda : g.zero + (lane & 7) * 8;      // padding pixels read the zero page, in place
+            cv_inc[i] = ok ? BK : 0;
+        }
+    };
+    auto conv_seek = [&](int kt) {
+        const int k0 = kt * BK;
+        cv_tap = k0 / g.Cin;
+        cv_c0 = k0 - cv_tap * g.Cin;
+        conv_tap(cv_tap);
+#pragma unroll
+        for (int i = 0; i < (CONV ? A_INST : 0); ++i) cv_ptr[i] += cv_inc[i] ? cv_c0 : 0;
+    };
+
     auto stage = [&](int kt, int buf) {
         f16* as = As + buf * BM * BK;
         f16* bs = Bs + buf * BN * BK;
@@ -148,20 +181,15 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
 #pragma unroll
             for (int i = 0; i < A_INST; ++i) glds16(a_src[i] + k0, as + (i * NW + wave) * 8 * BK);
         } else {
-            const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
-            const int ky = tap / g.ks, kx = tap - ky * g.ks;
 #pragma unroll
             for (int i = 0; i < A_INST; ++i) {
-                int iy = a_pix_y[i] + ky, ix = a_pix_x[i] + kx;
-                const f16* p;
-                if (g.ups) {   // coordinates are in the 2x-upsampled domain
-                    const bool ok = (iy >= 0) & (iy < 2 * g.H) & (ix >= 0) & (ix < 2 * g.Wd);
-                    p = ok ? a_img[i] + ((long)(iy >> 1) * g.Wd + (ix >> 1)) * g.lda + c0 : g.zero + (lane & 7) * 8;
-                } else {
-                    const bool ok = (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.Wd);
-                    p = ok ? a_img[i] + ((long)iy * g.Wd + ix) * g.lda + c0 : g.zero + (lane & 7) * 8;
-                }
-                glds16(p, as + (i * NW + wave) * 8 * BK);
+                glds16(cv_ptr[i], as + (i * NW + wave) * 8 * BK);
+                cv_ptr[i] += cv_inc[i];
+            }
+            cv_c0 += BK;
+            if (cv_c0 == g.Cin) {
+                cv_c0 = 0;
+                if (++cv_tap < g.ks * g.ks) conv_tap(cv_tap);
             }
         }
 #pragma unroll
@@ -189,6 +217,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     //  reading before it arrived there)
     const int nk_all = g.K / BK;
     const int kt0 = kz ? nk_all / 2 : 0, nk = g.splitk == 2 ? (kz ? nk_all : nk_all / 2) : nk_all;   // this workgroup's K tiles [kt0, nk)
+    if (CONV) conv_seek(kt0);
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
         if (kt0 + s < nk) stage(kt0 + s, s);
