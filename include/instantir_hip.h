@@ -53,10 +53,6 @@ typedef struct iir_gemm_desc {
     int64_t prefetch_bytes;        /*   so it is in the Infinity Cache for a LATER launch (next layers' weights) */
     void* splitk_ws;               /* optional split-K workspace (iir_gemm_splitk_workspace_bytes), ZEROED once by the  */
     int64_t splitk_ws_bytes;       /*   caller and private to one stream; lets tile = 0 pick the 2-slice form for long K  */
-    const float* ln_s; float ln_eps; /* optional fused nn.LayerNorm of the A rows (module/min_sdxl.py:541-560: norm1/2/3 feeding  */
-                                   /*   to_q|k|v, attn2.to_q, ff.net.0): A holds the RAW rows, W must be W * gamma, bias must     */
-                                   /*   include beta @ W^T, ln_s[n] = sum_k (W*gamma)[n][k] (fp32, 16-byte aligned); the launch   */
-                                   /*   returns rstd * (A @ W^T - mean * ln_s) + bias with the row statistics taken in-kernel    */
     void* Ct; int64_t ldct;        /* optional (PLAIN epilogue, no residual on those columns): output columns n >= tr_from */
     int32_t tr_from;               /*   are stored TRANSPOSED, Ct[(n - tr_from) * ldct + m] -- the V third of a fused       */
                                    /*   q|k|v projection lands as the V^T image iir_attention_d64_f16 consumes              */

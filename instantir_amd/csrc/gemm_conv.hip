@@ -52,7 +52,6 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     int tiles_m, tiles_n;
     int xm, rm, rn;           // XCD partition: xm x (8/xm) rectangles of rm x rn tiles
     const char* pf; int pf_lines;   // weight prefetch: 128-byte lines to pull towards the Infinity Cache
-    const float* ln_s; float ln_eps;   // fused LayerNorm of the A rows (LN kernels): s[n] = sum_k W'[n][k]; NULL = off
     int splitk;                     // 1 or 2 K slices per output tile (workgroups z = 0 / 1 of a tile share an XCD)
     long sk_bytes;                  // host only: bytes of the caller's split-K workspace
     float* sk_slabs; int* sk_cnt;   // split-K workspace: fp32 partial tiles [tile][z][BM*BN] and per-tile arrival counters
@@ -74,11 +73,7 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// LN: the A rows are RAW activations x and the launch computes LayerNorm(x) @ W^T without a LayerNorm kernel: W already
-// carries gamma (W' = W * gamma), every wave sums x and x^2 of its rows from the A fragments it loads anyway
-// (v_dot2c_f32_f16, under the MFMAs), and the epilogue forms rstd * (acc - mean * s[n]) with s[n] = sum_k W'[n][k];
-// beta @ W^T travels in the bias.
-template <int BM, int BN, int ST, bool CONV, int WAVES_M = 2, bool LN = false>
+template <int BM, int BN, int ST, bool CONV, int WAVES_M = 2>
 __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_kernel(const Geo g) {
     constexpr int NW = WAVES_M * 2, NT = 64 * NW;   // waves laid out WAVES_M x 2 over the tile
     constexpr int WM = BM / WAVES_M, WN = BN / 2;   // wave tile
@@ -235,20 +230,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
 #pragma unroll
         for (int j = 0; j < NI; ++j) bf[j] = *(const f16x8*)(bs + b_off[s] + j * 16 * 128);
     };
-    float rs[LN ? MI : 1], rq[LN ? MI : 1];       // per-lane partial sum / sum of squares of row i*16+frow (its 8 of every 32 k)
-    if (LN) for (int i = 0; i < MI; ++i) { rs[i] = 0.f; rq[i] = 0.f; }
     auto mma = [&](const f16x8 (&af)[MI], const f16x8 (&bf)[NI]) {
-        if (LN) {
-            const f16x2 one = {(f16)1.f, (f16)1.f};
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f16x2 v = {af[i][2 * e], af[i][2 * e + 1]};
-                    rs[i] = __builtin_amdgcn_fdot2(v, one, rs[i], false);
-                    rq[i] = __builtin_amdgcn_fdot2(v, v, rq[i], false);
-                }
-        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -268,18 +250,19 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
         frags(0, 0, a0, b0);
     }
     int cur = 0;
-    for (int kt = kt0; kt < nk; ++kt) {
-        frags(cur, 1, a1, b1);
+    for (int kt = kt0; kt + 1 < nk; ++kt) {                 // (last tile peeled: no conditional definition of the loop-carried
+        frags(cur, 1, a1, b1);                              //  fragment registers, which cost 80 v_mov per iteration)
         mma(a0, b0);
-        if (kt + 1 < nk) {
-            const int rem = nk - 2 - kt;                    // tiles that exist after kt+1
-            admit(rem < ST - 2 ? rem : ST - 2);
-            if (kt + ST < nk) stage(kt + ST, cur);          // tile kt's buffer is free: every wave finished reading it
-            cur = cur + 1 == ST ? 0 : cur + 1;
-            frags(cur, 0, a0, b0);
-        }
+        const int rem = nk - 2 - kt;                        // tiles that exist after kt+1
+        admit(rem < ST - 2 ? rem : ST - 2);
+        if (kt + ST < nk) stage(kt + ST, cur);              // tile kt's buffer is free: every wave finished reading it
+        cur = cur + 1 == ST ? 0 : cur + 1;
+        frags(cur, 0, a0, b0);
         mma(a1, b1);
     }
+    frags(cur, 1, a1, b1);
+    mma(a0, b0);
+    mma(a1, b1);
 
     // ---- epilogue, phase 1: registers -> LDS.  A lane holds row m = ..+frow and 4 consecutive columns n = ..+4*fq+{0..3};
     // stored straight to memory that is 16 rows x 32 B per instruction (16 B for the paired epilogues), which made the
@@ -323,18 +306,6 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
             for (int j = 0; j < NI; ++j) acc[i][j] += *(const f32x4*)(other + ((i * NI + j) * NT + tid) * 4);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    float ln_mean[LN ? MI : 1], ln_rstd[LN ? MI : 1];
-    if (LN) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {                    // the 4 lanes (fq = 0..3) that share row i*16+frow hold the four k-quarters
-            float a = rs[i], q = rq[i];
-            a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
-            a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
-            const float mean = a / (float)g.K;
-            ln_mean[i] = mean;
-            ln_rstd[i] = rsqrtf(fmaxf(q / (float)g.K - mean * mean, 0.f) + g.ln_eps);
-        }
-    }
     const bool paired = g.epi != IIR_EPI_PLAIN;
     const int cs = (paired ? BN : 2 * BN) + 32;                          // tile row stride in bytes: odd multiple of 32 mod 256
     char* ct = smem;
@@ -351,7 +322,6 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
                 const int n = n0 + lc;
                 if (n >= g.N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (LN) { const f32x4 s4 = *(const f32x4*)(g.ln_s + n); for (int t = 0; t < 4; ++t) v[t] = ln_rstd[i] * (v[t] - ln_mean[i] * s4[t]); }
                 if (g.bias) { f16x4 b = *(const f16x4*)(g.bias + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (rb) { f16x4 b = *(const f16x4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
@@ -371,7 +341,6 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
             for (int j = 0; j < NI; ++j) {
                 const int n = n0 + wn * WN + j * 16 + fq * 4;           // permuted column held by this lane
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (LN && n < g.N) { const f32x4 s4 = *(const f32x4*)(g.ln_s + n); for (int t = 0; t < 4; ++t) a[t] = ln_rstd[i] * (a[t] - ln_mean[i] * s4[t]); }
                 if (g.bias && n < g.N) { f16x4 ba = *(const f16x4*)(g.bias + n); for (int t = 0; t < 4; ++t) a[t] += (float)ba[t]; }
                 float b[4];
                 for (int t = 0; t < 4; ++t) b[t] = __shfl_xor(a[t], 32, 64);     // all lanes take part in the exchange
@@ -524,16 +493,6 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
         if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
         iir_launch(gemm_kernel<BM, BN, ST, true, WAVES_M>, grid, block, lds, stream, g);
     } else {
-        if (g.ln_s) {
-            if constexpr (ST == 2 && WAVES_M == 2) {
-                static bool attr_l = false;
-                if (!attr_l) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, false, WAVES_M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_l = true; }
-                iir_launch(gemm_kernel<BM, BN, ST, false, WAVES_M, true>, grid, block, lds, stream, g);
-                return iir_launch_status();
-            } else {
-                return IIR_EINVAL;          // the LayerNorm-fused form is built for the 2-stage 4-wave tiles only
-            }
-        }
         static bool attr_g = false;
         if (!attr_g) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, false, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
         iir_launch(gemm_kernel<BM, BN, ST, false, WAVES_M>, grid, block, lds, stream, g);
@@ -583,17 +542,6 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // tile each take half of K -- 36 KB instead of 2 x 28 KB of operands per K tile pair, i.e. 0.64x the L2 -> LDS fill that
     // bounds these launches -- and the last one to finish reduces (see the kernel).  Needs the caller's workspace.
     static const bool sk_on = !(getenv("IIR_SPLITK") && atoi(getenv("IIR_SPLITK")) == 0);
-    if (g.ln_s) {                         // LayerNorm-fused launches: plain cost-model tile, 2-stage ring
-        if (tile == 0) {
-            long best = -1;
-            for (int t = 1; t <= 5; ++t) {
-                const long blocks = (long)((g.M + kTiles[t].bm - 1) / kTiles[t].bm) * ((g.N + kTiles[t].bn - 1) / kTiles[t].bn);
-                const long cost = ((blocks + 511) / 512) * 2 * (kTiles[t].bm + kTiles[t].bn);
-                if (best < 0 || cost < best || (cost == best && kTiles[t].bm * kTiles[t].bn > kTiles[tile].bm * kTiles[tile].bn)) { best = cost; tile = t; }
-            }
-        }
-        tile = tile % 10 + 20;
-    }
     if (tile == 0 && sk_on && g.sk_slabs && g.K >= one_per_cu_min_k() && (g.K / BK) % 2 == 0) {
         const long need = splitk_ws_bytes(g.M, g.N);
         if (need > 0 && g.sk_bytes >= need) {
@@ -661,10 +609,6 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     g.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     g.pf = (const char*)d->prefetch; g.pf_lines = d->prefetch ? (int)(d->prefetch_bytes / 128) : 0;
     finish_geo(g);
-    if (d->ln_s) {
-        if (d->epi == IIR_EPI_SFT || d->N % 4 || (uintptr_t)d->ln_s % 16) return IIR_EINVAL;
-        g.ln_s = (const float*)d->ln_s; g.ln_eps = d->ln_eps;
-    }
     if (d->Ct) {
         if (d->epi != IIR_EPI_PLAIN || d->tr_from < 0 || d->tr_from >= d->N || d->tr_from % 8 || d->ldct < d->M) return IIR_EINVAL;
         g.Ct = (f16*)d->Ct; g.ldct = d->ldct; g.tr_from = d->tr_from;

@@ -36,7 +36,7 @@ import torch
 
 from . import ops
 from .config import UNetConfig
-from .packing import fold_layernorm, conv_weight_nhwc, pair_rows
+from .packing import conv_weight_nhwc, pair_rows
 from .weights import skip_channels
 
 F16 = torch.float16
@@ -142,8 +142,6 @@ class _Net:
         self._warena = None
         self.inkernel_prefetch = True
         self.fuse_qkv = os.environ.get("IIR_FUSE_QKV", "1") != "0"
-        self.fuse_ln = os.environ.get("IIR_FUSE_LN", "0") != "0" and self.fuse_qkv     # LayerNorm folded into the GEMM it feeds
-        self.lns = {}                      # fp32 row sums of the gamma-scaled weights (ops.gemm ln=)
         self._pack_encoder(sd)
 
     # ---- weight packing ---------------------------------------------------------------------
@@ -183,19 +181,12 @@ class _Net:
             p = f"{path}.transformer_blocks.{k}"
             self._pack_norm(sd, p + ".norm1")
             # one projection for q | k | v: the V third is written transposed by the GEMM's epilogue (iir_gemm_desc.Ct)
-            wqkv = torch.cat([self._t(sd, p + ".attn1.to_q.weight"), self._t(sd, p + ".attn1.to_k.weight"),
-                              self._t(sd, p + ".attn1.to_v.weight")], 0).contiguous()
-            if self.fuse_ln:       # norm1 -> q|k|v, norm2 -> attn2.to_q, norm3 -> ff1 computed inside those GEMMs (packing.fold_layernorm)
-                wqkv, self.lns[p + ".attn1.qkv"], self.w[p + ".attn1.qkv.b"] = fold_layernorm(
-                    wqkv, None, self._t(sd, p + ".norm1.weight"), self._t(sd, p + ".norm1.bias"))
-            self.w[p + ".attn1.qkv.w"] = wqkv
+            self.w[p + ".attn1.qkv.w"] = torch.cat([self._t(sd, p + ".attn1.to_q.weight"), self._t(sd, p + ".attn1.to_k.weight"),
+                                                    self._t(sd, p + ".attn1.to_v.weight")], 0).contiguous()
             self._pack_linear(sd, p + ".attn1.to_out.0")
             if self.cross:
                 self._pack_norm(sd, p + ".norm2")
                 self._pack_linear(sd, p + ".attn2.to_q")
-                if self.fuse_ln:
-                    self.w[p + ".attn2.to_q.w"], self.lns[p + ".attn2.to_q"], self.w[p + ".attn2.to_q.b"] = fold_layernorm(
-                        self.w[p + ".attn2.to_q.w"], None, self._t(sd, p + ".norm2.weight"), self._t(sd, p + ".norm2.bias"))
                 self._pack_linear(sd, p + ".attn2.to_k")
                 self._pack_linear(sd, p + ".attn2.to_v")
                 self._pack_linear(sd, p + ".attn2.to_out.0")
@@ -207,9 +198,6 @@ class _Net:
             self._pack_norm(sd, p + ".norm3")
             w1, b1 = self._t(sd, p + ".ff.net.0.proj.weight"), self._t(sd, p + ".ff.net.0.proj.bias")
             n = w1.shape[0] // 2
-            if self.fuse_ln:
-                w1, s1, b1 = fold_layernorm(w1, b1, self._t(sd, p + ".norm3.weight"), self._t(sd, p + ".norm3.bias"))
-                self.lns[p + ".ff1"] = pair_rows(s1[:n], s1[n:])
             self.w[p + ".ff1.w"] = pair_rows(w1[:n], w1[n:])          # GEGLU: value rows | gate rows
             self.w[p + ".ff1.b"] = pair_rows(b1[:n], b1[n:])
             self._pack_linear(sd, p + ".ff.net.2", p + ".ff2")
@@ -393,16 +381,11 @@ class _Net:
         m = A.mark()
         n = A.alloc(M, C)
         # -- self-attention (AttnProcessor2_0, attention_processor.py:370-402)
+        o.layernorm(h, n, w[p + ".norm1.g"], w[p + ".norm1.b"], 1e-5)
         qk = A.alloc(M, 2 * C)
         vt = A.alloc(C, M)
         wqkv = w[p + ".attn1.qkv.w"]
-        fl = self.fuse_ln
-        if not fl:
-            o.layernorm(h, n, w[p + ".norm1.g"], w[p + ".norm1.b"], 1e-5)
-        if fl:
-            o.gemm(h, wqkv, qk, bias=w[p + ".attn1.qkv.b"], ln=(self.lns[p + ".attn1.qkv"], 1e-5), prefetch=self._pf(wqkv),
-                   out_t=(vt, 2 * C))
-        elif self.fuse_qkv:
+        if self.fuse_qkv:
             o.gemm(n, wqkv, qk, prefetch=self._pf(wqkv), out_t=(vt, 2 * C))             # q | k, and V^T from the same launch
         else:
             o.gemm(n, wqkv[:2 * C], qk, prefetch=self._pf(wqkv))
@@ -413,13 +396,9 @@ class _Net:
                prefetch=self._pf(w[p + ".attn1.to_out.0.w"]))
         # -- decoupled cross-attention (TA_IPAttnProcessor2_0, attention_processor.py:1140-1195)
         if self.cross:
+            o.layernorm(h, n, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
             q = qk[:, :C]
-            if fl:
-                o.gemm(h, w[p + ".attn2.to_q.w"], q, bias=w[p + ".attn2.to_q.b"], ln=(self.lns[p + ".attn2.to_q"], 1e-5),
-                       prefetch=self._pf(w[p + ".attn2.to_q.w"]))
-            else:
-                o.layernorm(h, n, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
-                o.gemm(n, w[p + ".attn2.to_q.w"], q, prefetch=self._pf(w[p + ".attn2.to_q.w"]))
+            o.gemm(n, w[p + ".attn2.to_q.w"], q, prefetch=self._pf(w[p + ".attn2.to_q.w"]))
             cfg = self.cfg
             nip, ipad = cfg.num_ip_tokens, (cfg.num_ip_tokens + 7) // 8 * 8
             kv = st["kv"][p]
@@ -429,13 +408,9 @@ class _Net:
             o.gemm(a, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h,
                    prefetch=self._pf(w[p + ".attn2.to_out.0.w"]))
         # -- GEGLU feed-forward (module/min_sdxl.py:502-528)
+        o.layernorm(h, n, w[p + ".norm3.g"], w[p + ".norm3.b"], 1e-5)
         f = A.alloc(M, 4 * C)
-        if fl:
-            o.gemm(h, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, ln=(self.lns[p + ".ff1"], 1e-5),
-                   prefetch=self._pf(w[p + ".ff1.w"]))
-        else:
-            o.layernorm(h, n, w[p + ".norm3.g"], w[p + ".norm3.b"], 1e-5)
-            o.gemm(n, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.w"]))
+        o.gemm(n, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.w"]))
         o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]), splitk_ws=self._skws)
         A.release(m)
 

@@ -32,7 +32,6 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
-        ("ln_s", C.c_void_p), ("ln_eps", C.c_float),
         ("Ct", C.c_void_p), ("ldct", C.c_int64), ("tr_from", C.c_int32),
     ]
 

@@ -104,7 +104,7 @@ def splitk_workspace(M, N, device):
 
 
 def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
-         tile=0, prefetch=None, splitk_ws=None, out_t=None, ln=None):
+         tile=0, prefetch=None, splitk_ws=None, out_t=None):
     """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues).
     out_t = (Ct, tr_from): output columns >= tr_from go, transposed, to Ct[n - tr_from, m]; `out` then is (M, tr_from)."""
     _chk2d(a, "a"); _chk2d(w, "w"); _chk2d(out, "out")
@@ -134,8 +134,6 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
         d.prefetch, d.prefetch_bytes = prefetch
     if splitk_ws is not None:
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
-    if ln is not None:                # (s fp32 (N,), eps): fused LayerNorm of the rows of `a`, see packing.fold_layernorm
-        d.ln_s, d.ln_eps = ln[0].data_ptr(), ln[1]
     if out_t is not None:
         ct, tr_from = out_t
         _chk2d(ct, "out_t")

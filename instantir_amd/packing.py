@@ -25,15 +25,3 @@ def conv_weight_nhwc(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tenso
         w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[3]))
     return w.contiguous()
 
-
-def fold_layernorm(w: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor):
-    """LayerNorm(x) @ W^T + b  ==  rstd * (x @ W'^T - mean * s) + b'  with  W' = W * gamma (per input feature),
-    s[n] = sum_k W'[n][k] (of the fp16-ROUNDED W', what the MFMA multiplies), b' = beta @ W^T + b.
-    Returns (W' fp16, s fp32, b' fp16) for `ops.gemm(..., ln=(s, eps))`."""
-    w32 = w.float()
-    wg = (w32 * gamma.float()[None, :]).to(torch.float16)
-    s = wg.float().sum(dim=1).contiguous()
-    b = w32 @ beta.float()
-    if bias is not None:
-        b = b + bias.float()
-    return wg.contiguous(), s, b.to(torch.float16).contiguous()

@@ -116,46 +116,6 @@ def test_gemm_transposed_column_range(dev, M, C, tile):
     assert qk[:, 2 * C:].abs().max().item() == 0 and vt[:, M:].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("M,N,K,mode,tile", [(256, 320, 640, "plain", 0), (300, 132, 128, "plain", 2), (2048, 1280, 1280, "plain", 0),
-                                              (512, 1280, 640, "geglu", 0), (130, 96, 256, "geglu", 3), (256, 3 * 128, 128, "qkv", 0),
-                                              (1024, 640, 1280, "plain", 5), (64, 64, 64, "plain", 1)])
-def test_gemm_fused_layernorm(dev, M, N, K, mode, tile):
-    """`ln=`: LayerNorm(x) @ W^T + b computed from the RAW rows (statistics taken inside the K loop, gamma folded into W,
-    beta into the bias) == F.layer_norm followed by the plain product; rows with a large common offset included."""
-    from instantir_amd import ops
-    from instantir_amd.packing import fold_layernorm, pair_rows
-    g = torch.Generator().manual_seed(M + N + K)
-    x = _rand(g, M, K) * 1.7 + 0.8
-    x[::7] += 3.0                                              # mean >> std on some rows
-    gamma, beta = (_rand(g, K) * 0.3 + 1.0), _rand(g, K) * 0.2
-    w, b = _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
-    y = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)
-    full = y @ w.float().T + b.float()
-    wg, s_, bf = fold_layernorm(w, b, gamma, beta)
-    xd = x.to(dev)
-    if mode == "geglu":
-        want = full[:, :N // 2] * F.gelu(full[:, N // 2:])
-        out = torch.empty(M, N // 2, dtype=torch.half, device=dev)
-        ops.gemm(xd, pair_rows(wg[:N // 2], wg[N // 2:]).to(dev), out, bias=pair_rows(bf[:N // 2], bf[N // 2:]).to(dev), epi=ops.EPI_GEGLU,
-                 ln=(pair_rows(s_[:N // 2], s_[N // 2:]).contiguous().to(dev), 1e-5), tile=tile)
-        torch.cuda.synchronize()
-        _close(out, want, rtol=4e-3, atol=4e-3, what="LN+GEGLU")
-    elif mode == "qkv":
-        C = N // 3
-        qk = torch.empty(M, 2 * C, dtype=torch.half, device=dev)
-        vt = torch.empty(C, M, dtype=torch.half, device=dev)
-        ops.gemm(xd, wg.to(dev), qk, bias=bf.to(dev), ln=(s_.to(dev), 1e-5), out_t=(vt, 2 * C), tile=tile)
-        torch.cuda.synchronize()
-        _close(qk, full[:, :2 * C], rtol=4e-3, atol=4e-3, what="LN+qk")
-        _close(vt, full[:, 2 * C:].T, rtol=4e-3, atol=4e-3, what="LN+V^T")
-    else:
-        res = _rand(g, M, N)
-        out = torch.empty(M, N, dtype=torch.half, device=dev)
-        ops.gemm(xd, wg.to(dev), out, bias=bf.to(dev), res=res.to(dev), ln=(s_.to(dev), 1e-5), tile=tile)
-        torch.cuda.synchronize()
-        _close(out, full + res.float(), rtol=4e-3, atol=4e-3, what="LN+gemm")
-
-
 def test_gemm_strided_a_and_scale(dev):
     from instantir_amd import ops
     g = torch.Generator().manual_seed(3)
