@@ -17,13 +17,18 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    # IIR_DIST_BACKEND=gloo + fewer devices than ranks: rehearsal of the N > 1 flow on a one-GPU box (ranks share the card;
+    # RCCL itself refuses two ranks on one device)
+    backend = os.environ.get("IIR_DIST_BACKEND", "nccl" if use_gpu else "gloo")
+    if use_gpu and backend != "nccl":
+        local = local % torch.cuda.device_count()
     device = torch.device(f"cuda:{local}" if use_gpu else "cpu")
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local, device
 
 
