@@ -67,6 +67,8 @@ int iir_gemm_f16(const iir_gemm_desc* d, void* stream);
 int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired);
 /* bytes of split-K workspace an (M, N) problem can use (0: the split form does not apply to it) */
 int64_t iir_gemm_splitk_workspace_bytes(int32_t M, int32_t N);
+/* 1 if a tile = 0 launch of this problem with a workspace of ws_bytes takes the two-slice split-K form (128x160 tile) */
+int iir_gemm_uses_splitk(int32_t M, int32_t N, int32_t K, int64_t ws_bytes);
 /* output-tile width BN of tile id `tile` (1..6) */
 int iir_gemm_tile_bn(int32_t tile);
 

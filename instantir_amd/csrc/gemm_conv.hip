@@ -536,19 +536,22 @@ long splitk_ws_bytes(int M, int N) {
     return t * 2 <= 256 ? SK_CNT_BYTES + t * 2 * 128 * 160 * (long)sizeof(float) : 0;
 }
 
+bool uses_splitk(int M, int N, int K, long ws_bytes) {
+    const long need = splitk_ws_bytes(M, N);
+    return K >= one_per_cu_min_k() && (K / BK) % 2 == 0 && need > 0 && ws_bytes >= need;
+}
+
 int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
-    // Long-K problems too small to fill the chip with 128x160 tiles (level-2 ff2, K = 5120, and 3x3 convs, K = 11520 /
-    // 23040, all M x N = 2048 x 1280): instead of one 64x160 workgroup per CU over all of K, two 128x160 workgroups per
-    // tile each take half of K -- 36 KB instead of 2 x 28 KB of operands per K tile pair, i.e. 0.64x the L2 -> LDS fill that
-    // bounds these launches -- and the last one to finish reduces (see the kernel).  Needs the caller's workspace.
-    static const bool sk_on = !(getenv("IIR_SPLITK") && atoi(getenv("IIR_SPLITK")) == 0);
-    if (tile == 0 && sk_on && g.sk_slabs && g.K >= one_per_cu_min_k() && (g.K / BK) % 2 == 0) {
-        const long need = splitk_ws_bytes(g.M, g.N);
-        if (need > 0 && g.sk_bytes >= need) {
-            Geo g2 = g;
-            g2.splitk = 2;
-            return launch<128, 160, 3>(g2, conv, stream);
-        }
+    // Two-slice split-K, taken only when the caller hands over a workspace: two 128x160 workgroups per tile each take half of
+    // K and the last one to finish reduces (see the kernel).  Meant for long-K problems too small to fill the chip with
+    // 128x160 tiles (M x N = 2048 x 1280 at K = 5120 / 11520); MEASURED SLOWER than one 64x160 workgroup per CU over all
+    // of K on exactly those (51.8 vs 44.8 us warm at K = 5120, equal at K = 11520, 73.9 vs 73.0 ms per step): the agent-scope
+    // release per workgroup and the fp32 slab round trip cost more than the smaller operand fill saves.  The engine does
+    // not pass a workspace unless IIR_SPLITK=1.
+    if (tile == 0 && g.sk_slabs && uses_splitk(g.M, g.N, g.K, g.sk_bytes)) {
+        Geo g2 = g;
+        g2.splitk = 2;
+        return launch<128, 160, 3>(g2, conv, stream);
     }
     // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64, 4: 128x160, 5: 64x160}; t + 10*stages selects the ring depth.
     if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
@@ -590,6 +593,7 @@ void finish_geo(Geo& g) {
 extern "C" int iir_gemm_tile_bn(int32_t tile) { tile %= 10; return (tile >= 1 && tile <= 6) ? kTiles[tile].bn : -1; }
 
 extern "C" int64_t iir_gemm_splitk_workspace_bytes(int32_t M, int32_t N) { return splitk_ws_bytes(M, N); }
+extern "C" int iir_gemm_uses_splitk(int32_t M, int32_t N, int32_t K, int64_t ws_bytes) { return uses_splitk(M, N, K, ws_bytes) ? 1 : 0; }
 
 extern "C" int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired) { return pick_tile(M, N, paired != 0, K); }
 

@@ -247,7 +247,7 @@ class _Net:
         plain = self.w
         first = not self.units
         self._gnws = ops.gn_workspace(self.device, 64, self.cfg.norm_groups)
-        if self._skws is None:     # split-K workspace (zeroed once; this network's launches share one stream order)
+        if self._skws is None and os.environ.get("IIR_SPLITK", "0") == "1":     # split-K measured slower: opt-in only
             self._skws = torch.zeros(4096 + 256 * 128 * 160 * 4, dtype=torch.uint8, device=self.device)
         if first:
             self._use_log = []

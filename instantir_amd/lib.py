@@ -88,6 +88,7 @@ _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "iir_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "iir_gemm_splitk_workspace_bytes": (C.c_int64, [_I32, _I32]),
+    "iir_gemm_uses_splitk": (C.c_int, [_I32, _I32, _I32, _I64]),
     "iir_gemm_pick_tile": (C.c_int, [_I32, _I32, _I32, _I32]),
     "iir_gemm_tile_bn": (C.c_int, [_I32]),
     "iir_conv2d_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), _P]),

@@ -127,9 +127,9 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     if res is not None:
         _chk2d(res, "res")
         d.res, d.ldr = res.data_ptr(), res.stride(0)
-    if tile == 0:
-        tile = auto_tile(M, N, epi != EPI_PLAIN, K)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
+    if tile == 0:       # the library decides; resolve the same choice here only to NAME the launch for the profiler
+        tile = 4 if splitk_ws is not None and L.load().iir_gemm_uses_splitk(M, N, K, splitk_ws.numel()) else auto_tile(M, N, epi != EPI_PLAIN, K)
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
     if splitk_ws is not None:
@@ -175,9 +175,10 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     Hi, Wi = (2 * H, 2 * Wd) if upsample else (H, Wd)
     pad2 = 1 if pad_mode == 1 else 2 * (ksize // 2)
     Mo = R * ((Hi + pad2 - ksize) // stride + 1) * ((Wi + pad2 - ksize) // stride + 1)
-    if tile == 0:
-        tile = auto_tile(Mo, Cout, epi != EPI_PLAIN, ksize * ksize * Cin)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
+    if tile == 0:       # as in gemm(): the library decides, this only names the launch
+        Kc = ksize * ksize * Cin
+        tile = 4 if splitk_ws is not None and L.load().iir_gemm_uses_splitk(Mo, Cout, Kc, splitk_ws.numel()) else auto_tile(Mo, Cout, epi != EPI_PLAIN, Kc)
     d.zero_page = zero_page(x.device).data_ptr()
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
