@@ -506,12 +506,13 @@ constexpr TileShape kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 1
 // Tile choice: the per-CU operand fill rate (L2 -> LDS, ~50-70 GB/s) bounds these launches, so pick the
 // shape that minimises the bytes the busiest CU has to pull.  Two workgroups per CU overlap each other's
 // load latency, so capacity is counted in 512 slots: cost = ceil(blocks / 512) * 2 * (BM + BN) [* K * 2 B].
-// One workgroup per CU leaves nothing else to hide the L2 -> LDS latency: long-K launches of that kind take the 64x160
-// tile with a deeper ring.  Cold-weight sweep (tools/tilebench.py, us): 2048x1280x5120  128x64/2 67.0 | 64x160/3 47.3 | /4 46.1;
-// 2048x1280x1280  128x64/2 21.9 | 64x160/3 16.7 | /4 16.3 -- but inside the loop (weights prefetched by the previous
-// launch, a second stream sharing the CUs) extending the rule to K = 1280 measured 79.4 vs 78.2 ms/step, so it stays
-// at K >= 2560 / 3 stages (IIR_T5_MINK / IIR_T5_STAGES override for experiments).
-int one_per_cu_min_k() { static const int v = [] { const char* e = getenv("IIR_T5_MINK"); return e ? atoi(e) : 2560; }(); return v; }
+// One workgroup per CU leaves nothing else to hide the L2 -> LDS latency: launches that fit one 64x160 workgroup per CU
+// (M x N = 2048 x 1280: the level-2 projections) take that tile with a 3-deep ring instead of 320 128x64 workgroups.
+// Cold-weight sweep (tools/tilebench.py, us): 2048x1280x1280  128x64/2 21.9 | 64x160/3 16.7 | /4 16.3;  2048x1280x5120
+// 128x64/2 67.0 | 64x160/3 47.3 | /4 46.1.  In the loop: K >= 2560 only 72.8 ms/step, K >= 1280 71.8 (3 stages), 72.7
+// (4 stages) -- same call.  (With the first-generation epilogue the K = 1280 extension had measured as a loss.)
+// IIR_T5_MINK / IIR_T5_STAGES override for experiments.
+int one_per_cu_min_k() { static const int v = [] { const char* e = getenv("IIR_T5_MINK"); return e ? atoi(e) : 1280; }(); return v; }
 int one_per_cu_stages() { static const int v = [] { const char* e = getenv("IIR_T5_STAGES"); return e ? atoi(e) : 3; }(); return v; }
 
 int pick_tile(int M, int N, bool paired, int K = 0) {
