@@ -227,8 +227,8 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {args.size}x{args.size}, batch 1/GPU, cfg 7.0 (2 rows), 30-step DDIM "
                                    f"timetable, preview_start 0, full SDXL+TA-IP UNet x2 + Aggregator per step"
                                    + (" [TINY DEBUG GEOMETRY]" if args.tiny else ""),
-                       "images_per_gpu": B, "latent": [Hl, Hl], "params": n_params, "graph": not args.no_graph,
-                       "step_tflop_model": STEP_TFLOP, "model_tflops_per_gpu": round(STEP_TFLOP * args.steps / dt, 1),
+                       "images_per_gpu": B, "latent": [Hl, Hl], "weight_elements": n_params, "graph": not args.no_graph,
+                       "algorithmic_tflop_per_step": STEP_TFLOP, "algorithmic_tflops_per_gpu": round(STEP_TFLOP * args.steps / dt, 1),
                        "images_per_s_30step": round(world / (30 * dt / args.steps + (((vae_ms or {}).get("decode_ms", 0) + (vae_ms or {}).get("encode_ms", 0)) * 1e-3)), 4),
                        "vae": vae_ms, "finite": finite,
                        "setup_s": round(setup_s, 1)},
