@@ -652,9 +652,9 @@ class HipUNet(_Net):
         self._join_prefetch()
         return enc
 
-    def decode(self, enc, st, down_res=None, mid_res=None, res_scale=None):
+    def decode(self, enc, st, down_res=None, mid_res=None, res_scale=None, late_event=None):
         """Second half (residual adds, up blocks, conv_out) on the state returned by `encode`."""
-        out = self._decode(enc, st, down_res, mid_res, res_scale)
+        out = self._decode(enc, st, down_res, mid_res, res_scale, late_event)
         self._join_prefetch()
         return out
 
@@ -670,7 +670,9 @@ class HipUNet(_Net):
         x, h, wd, skips = self._down_and_mid(x, R, H, W, temb_all, ada, st)
         return x, h, wd, skips, temb_all, ada
 
-    def _decode(self, enc, st, down_res, mid_res, res_scale):
+    def _decode(self, enc, st, down_res, mid_res, res_scale, late_event=None, late_from_block=1):
+        """`late_event`: recorded on another stream once the residuals of the shallow skips are complete; the decoder waits
+        for it only before up block `late_from_block` (the deep residuals it consumes first are already there)."""
         cfg, o, w, A = self.cfg, self.o, self.w, self.arena
         R = st["R"]
         x, h, wd, skips, temb_all, ada = enc
@@ -680,6 +682,8 @@ class HipUNet(_Net):
         nb = len(rev)
         pending_mid = mid_res            # added to the mid output when it is copied into the first concat
         for i, c in enumerate(rev):
+            if late_event is not None and i == late_from_block:
+                torch.cuda.current_stream().wait_event(late_event)
             for j in range(cfg.layers_per_block + 1):
                 sk, sh, sw = skips.pop()
                 k = len(skips)           # index of this skip in push order
@@ -713,6 +717,8 @@ class HipAggregator(_Net):
 
     def __init__(self, cfg: UNetConfig, sd: Dict[str, torch.Tensor], device):
         super().__init__(cfg, sd, False, device)
+        self.defer_shallow = False
+        self._late = []
         self._pack_conv3(sd, "ref_conv_in", CPAD)
         names = [f"controlnet_down_blocks.{k}" for k in range(len(skip_channels(cfg)))] + ["controlnet_mid_block"]
         for p in names:
@@ -785,7 +791,22 @@ class HipAggregator(_Net):
         o.conv2d(lq.view(R, H, W, CPAD), w["conv_in.w"], x, bias=w["conv_in.b"], y_img_rows=2 * H * W)
         o.conv2d(preview.view(R, H, W, CPAD), w["ref_conv_in.w"], x[H * W:], bias=w["ref_conv_in.b"], y_img_rows=2 * H * W)
         xm, h2, wd, skips = self._down_and_mid(x, R, 2 * H, W, temb_all, ada, st)
-        for k, (s, sh, sw) in enumerate(skips):
-            self._sft(f"controlnet_down_blocks.{k}", s, R, sh, sw, self._out[k])
+        # heads in the order the UNet decoder consumes their residuals: mid, then the deepest skips.  With `defer_shallow`
+        # the heads of the skips used by the LAST two up blocks are left to `late_heads()` (the caller runs it on another
+        # stream, beside the decoder's first up block).
         self._sft("controlnet_mid_block", xm, R, h2, wd, self._out_mid)
+        n_deep = cfg.layers_per_block + 1                       # skips popped by up block 0
+        self._late = []
+        for k in reversed(range(len(skips))):
+            s, sh, sw = skips[k]
+            if self.defer_shallow and k < len(skips) - n_deep:
+                self._late.append((k, s, sh, sw))
+            else:
+                self._sft(f"controlnet_down_blocks.{k}", s, R, sh, sw, self._out[k])
+        self._late_R = R
         return self._out, self._out_mid
+
+    def late_heads(self):
+        for k, s, sh, sw in self._late:
+            self._sft(f"controlnet_down_blocks.{k}", s, self._late_R, sh, sw, self._out[k])
+        self._late = []

@@ -99,6 +99,7 @@ class InstantIRPipeline:
         self._graphs = {}
         self.use_graphs = True
         self.overlap_streams = True
+        self.overlap_sft = os.environ.get("IIR_OVERLAP_SFT", "1") != "0"     # shallow SFT heads beside the decoder's first up block
         self._guidance_scale = 7.0
 
     # ---- reference surface ----------------------------------------------------------------------
@@ -590,9 +591,20 @@ class _DenoiseLoop:
                 cond = self.prev16
             else:
                 cond = self.ref16 if self.ref16 is not None else self.lq16
+            p._agg.defer_shallow = p.overlap_sft
             down, mid = p._agg.forward(self.lq16, cond, self.t_dev, self.st_agg)
             main.wait_event(join)
-            eps = p._unet.decode(enc, self.st, down, mid, self.res_scale)
+            late = None
+            if p.overlap_sft:
+                # the SFT heads of the shallow skips (consumed by the last up blocks) run on the side stream beside the
+                # decoder's first up block
+                f2, late = torch.cuda.Event(), torch.cuda.Event()
+                f2.record(main)
+                self.side.wait_event(f2)
+                with torch.cuda.stream(self.side):
+                    p._agg.late_heads()
+                    late.record(self.side)
+            eps = p._unet.decode(enc, self.st, down, mid, self.res_scale, late_event=late)
             self._sched(eps, use_noise, want_x0)
             return
         if mode != "unet":
@@ -603,6 +615,7 @@ class _DenoiseLoop:
                 cond = self.prev16
             else:
                 cond = self.ref16 if self.ref16 is not None else self.lq16               # :1579-1582
+            p._agg.defer_shallow = False
             down, mid = p._agg.forward(self.lq16, cond, self.t_dev, self.st_agg)           # :1591-1599
         eps = p._unet.forward(self.lat16, self.t_dev, self.st, down, mid, self.res_scale if down is not None else None)
         self._sched(eps, use_noise, want_x0)
