@@ -24,7 +24,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with one v_exp and one v_rcp (1 ulp) instead of the IEEE division sequence: the GroupNorm + SiLU pass
+// evaluates it for every element of every resnet input.
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 // exact-erf GELU (F.gelu default, the GEGLU gate of module/min_sdxl.py:502-528).  erf by Abramowitz-Stegun 7.1.26
 // (|error| < 1.5e-7, branch-free: one v_rcp, one v_exp, five FMAs) instead of libm's piecewise erff: the GEGLU epilogue
 // evaluates it 10240 times per 128x160 tile.  Against torch's fp64 GELU the fp32 result is within 5e-7 absolute.

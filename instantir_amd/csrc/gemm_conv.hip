@@ -326,7 +326,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
                 if (rb) { f16x4 b = *(const f16x4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
                 else if (g.act == IIR_ACT_GELU) for (int t = 0; t < 4; ++t) v[t] = gelu_erf_f(v[t]);
-                else if (g.act == IIR_ACT_QUICKGELU) for (int t = 0; t < 4; ++t) v[t] = v[t] / (1.0f + __expf(-1.702f * v[t]));
+                else if (g.act == IIR_ACT_QUICKGELU) for (int t = 0; t < 4; ++t) v[t] = v[t] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[t]));
                 f16x4 o;
                 for (int t = 0; t < 4; ++t) o[t] = (f16)v[t];
                 *(f16x4*)(ct + lr * cs + lc * 2) = o;
