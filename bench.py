@@ -64,10 +64,26 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
-    ap.add_argument("--prefetch", action="store_true", help="enable the side-stream weight prefetcher (experimental)")
     ap.add_argument("--no-inkernel-prefetch", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no encoder/previewer overlap)")
     args = ap.parse_args()
+
+    # ---- launch contract: `--gpus N` must mean N ranks.  Under torch.distributed.run WORLD_SIZE says how many there are;
+    # a bare `python bench.py --gpus N` (N > 1) starts the N ranks itself as a CHILD process group (torchrun on
+    # 127.0.0.1) -- decided here, before anything touches the GPU (a process that has initialised HIP must never exec).
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if env_world == 0 and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"--gpus {args.gpus} without a launcher: starting {args.gpus} ranks via torch.distributed.run")
+        raise SystemExit(subprocess.run(cmd).returncode)
+    if env_world and env_world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: the launcher and the flag disagree")
 
     from instantir_amd import lib, ops, parallel, weights as W
     from instantir_amd.config import UNetConfig
@@ -82,16 +98,32 @@ def main():
     Hl = args.size // 8
     B, guidance, n_steps_sched = 1, 7.0, 30
 
-    log(f"rank {rank}/{world} on {dev}: generating weights")
-    # ---- frozen weights: rank 0 generates, everyone receives them over RCCL -----------------------
+    ranks_info = parallel.describe_ranks(rank, world, local, dev)      # every rank's device + backend, checked distinct under RCCL
+    # ---- frozen weights: ONLY rank 0 generates them; every other rank allocates empty tensors of the same inventory
+    # and receives the values over RCCL/xGMI.  The broadcast is timed on its own, outside the
+    # timed region of the metric.
     t0 = time.time()
     seed = 1234
-    sd = W.synth_state_dict(W.unet_specs(cfg), seed, device=dev)
-    sda = W.synth_state_dict(W.aggregator_specs(cfg), seed + 1, device=dev)
-    lora = W.synth_state_dict(W.lora_specs(cfg), seed + 2, device=dev)
+    inv = [(W.unet_specs(cfg), seed), (W.aggregator_specs(cfg), seed + 1), (W.lora_specs(cfg), seed + 2)]
+    if rank == 0:
+        log(f"rank 0/{world} on {dev}: generating weights")
+        sd, sda, lora = (W.synth_state_dict(sp, sd_seed, device=dev) for sp, sd_seed in inv)
+    else:
+        sd, sda, lora = ({n: torch.empty(shape, dtype=torch.float16, device=dev) for n, shape, _ in sp} for sp, _ in inv)
+    bcast = None
     if world > 1:
+        torch.cuda.synchronize()
+        parallel.barrier()
+        tb = time.perf_counter()
+        nbytes = 0
         for d in (sd, sda, lora):
             parallel.broadcast_state_dict(d, 0)
+            nbytes += sum(v.numel() * v.element_size() for v in d.values())
+        torch.cuda.synchronize()
+        parallel.barrier()
+        tb = parallel.max_over_ranks(time.perf_counter() - tb, dev)
+        bcast = {"bytes": nbytes, "seconds": round(tb, 3), "GB_per_s": round(nbytes / tb / 1e9, 1)}
+        log(f"weights broadcast from rank 0: {nbytes / 1e9:.2f} GB in {tb:.2f} s")
     pipe = InstantIRPipeline(cfg, sd, scheduler=DDIMScheduler(), device=dev)
     pipe.aggregator.load_state_dict(sda)
     pipe.prepare_previewers(lora, lora_alpha=cfg.lora_rank // 8)
@@ -99,7 +131,6 @@ def main():
     pipe.overlap_streams = not args.no_overlap
     pipe._build()
     for net in (pipe._unet, pipe._unet_prev, pipe._agg):
-        net.prefetch = args.prefetch
         net.inkernel_prefetch = not args.no_inkernel_prefetch
     log(f"engines built ({time.time() - t0:.1f} s)")
     n_params = sum(v.numel() for v in sd.values()) + sum(v.numel() for v in sda.values())
@@ -231,7 +262,7 @@ def main():
                        "algorithmic_tflop_per_step": STEP_TFLOP, "algorithmic_tflops_per_gpu": round(STEP_TFLOP * args.steps / dt, 1),
                        "images_per_s_30step": round(world / (30 * dt / args.steps + (((vae_ms or {}).get("decode_ms", 0) + (vae_ms or {}).get("encode_ms", 0)) * 1e-3)), 4),
                        "vae": vae_ms, "finite": finite,
-                       "setup_s": round(setup_s, 1)},
+                       "setup_s": round(setup_s, 1), "world": world, "ranks": ranks_info, "weight_broadcast": bcast},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -114,9 +114,6 @@ class _RecDict(dict):
         return dict.__getitem__(self, k)
 
 
-PREFETCH_BLOCKS = 48      # workgroups of the weight prefetcher: a trickle beside the GEMMs, not a competitor
-
-
 class _Net:
     """Shared machinery: packed weights, arena, resnet / transformer executors."""
 
@@ -133,10 +130,6 @@ class _Net:
         # transformer block / SFT head, in execution order inside ONE contiguous weight arena
         self.units: List[tuple] = []
         self._use_log: Optional[list] = None
-        self._unit_idx = 0
-        self.prefetch = False     # side-stream weight prefetch: measured slower under hipGraph replay
-        self._pf_stream = None
-        self._pf_forked = False
         self._gnws = None
         self._skws = None
         self._warena = None
@@ -295,25 +288,12 @@ class _Net:
         self._use_log = None
 
     def _unit(self, name):
-        """Called at the start of every resnet / transformer block / SFT head."""
+        """Called at the start of every resnet / transformer block / SFT head: marks where a block's weights begin in the
+        execution-ordered weight arena (recorded once, in the sizing dry run).  (A side-stream prefetcher used to hang off
+        these marks; it measured slower under graph replay and its third-stream fork inside a capture crashed
+        hipStreamEndCapture, so it was removed in round 2 -- the in-kernel tail prefetch `_pf` is the form that pays.)"""
         if self._use_log is not None:
             self._use_log.append(("unit", name))
-            return
-        if self.o is not ops:
-            return
-        k = self._unit_idx
-        self._unit_idx += 1
-        if not self.prefetch or k + 1 >= len(self.units) or self.units[k + 1][1] < (1 << 20):
-            return
-        cur = torch.cuda.current_stream()
-        if self._pf_stream is None:
-            self._pf_stream = torch.cuda.Stream(device=self.device)
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        self._pf_stream.wait_event(ev)
-        with torch.cuda.stream(self._pf_stream):
-            ops.prefetch(self.units[k + 1][0], self.units[k + 1][1], PREFETCH_BLOCKS)
-        self._pf_forked = True
 
     import os as _os
     PF_MULT = float(_os.environ.get("IIR_PF_MULT", "1"))
@@ -333,15 +313,6 @@ class _Net:
 
     def _begin(self):
         self.arena.reset()
-        self._unit_idx = 0
-
-    def _join_prefetch(self):
-        """The prefetch stream forked from the compute stream must rejoin it (hipGraph capture rule)."""
-        if self._pf_forked:
-            ev = torch.cuda.Event()
-            ev.record(self._pf_stream)
-            torch.cuda.current_stream().wait_event(ev)
-            self._pf_forked = False
 
     # ---- blocks -----------------------------------------------------------------------------
     def _resnet(self, path, x, R, H, W, temb_all, out=None, eps=1e-5):
@@ -640,23 +611,17 @@ class HipUNet(_Net):
         per-row scale of the residuals (cond_scale, pipelines/sdxl_instantir.py:1602-1603).
         Returns eps as an (R*H*W, 4) fp16 NHWC view into the arena (valid until the next forward)."""
         self._begin()
-        out = self._forward(sample, t_dev, st, down_res, mid_res, res_scale)
-        self._join_prefetch()
-        return out
+        return self._forward(sample, t_dev, st, down_res, mid_res, res_scale)
 
     def encode(self, sample, t_dev, st):
         """First half (embeddings, conv_in, down blocks, mid block): independent of the Aggregator residuals,
         so the caller may run it on a side stream while the previewer UNet / Aggregator run."""
         self._begin()
-        enc = self._encode(sample, t_dev, st)
-        self._join_prefetch()
-        return enc
+        return self._encode(sample, t_dev, st)
 
     def decode(self, enc, st, down_res=None, mid_res=None, res_scale=None, late_event=None):
         """Second half (residual adds, up blocks, conv_out) on the state returned by `encode`."""
-        out = self._decode(enc, st, down_res, mid_res, res_scale, late_event)
-        self._join_prefetch()
-        return out
+        return self._decode(enc, st, down_res, mid_res, res_scale, late_event)
 
     def _forward(self, sample, t_dev, st, down_res, mid_res, res_scale):
         return self._decode(self._encode(sample, t_dev, st), st, down_res, mid_res, res_scale)
@@ -759,9 +724,7 @@ class HipAggregator(_Net):
         """lq, preview: (R*H*W, 64) fp16 NHWC latents.  Returns (list of 9 residuals, mid residual),
         each (R*h*w, C) fp16 NHWC, un-scaled (conditioning_scale = 1, module/aggregator.py:963-964)."""
         self._begin()
-        out = self._forward(lq, preview, t_dev, st)
-        self._join_prefetch()
-        return out
+        return self._forward(lq, preview, t_dev, st)
 
     def _sft(self, p, s, R, h2, wd, out):
         """SFT + zero 1x1 on a (R, 2h, w, C) map: cond = top half, h = bottom half.

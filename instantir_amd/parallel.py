@@ -32,6 +32,21 @@ def init_from_env():
     return rank, world, local, device
 
 
+def describe_ranks(rank: int, world: int, local: int, device):
+    """[{rank, device, backend}] for every rank (gathered on all ranks).  Under RCCL every rank must own a distinct GPU:
+    two ranks on one device mean the launcher and the visible-device list disagree -- fail loudly, do not measure it."""
+    me = {"rank": rank, "device": str(device), "backend": dist.get_backend() if dist.is_initialized() else "none"}
+    if not dist.is_initialized() or world == 1:
+        return [me]
+    out: List[dict] = [None] * world
+    dist.all_gather_object(out, me)
+    if me["backend"] == "nccl":
+        devs = [o["device"] for o in out]
+        if len(set(devs)) != len(devs):
+            raise RuntimeError(f"RCCL ranks share a device: {devs}")
+    return out
+
+
 def shard_range(n_items: int, rank: int, world: int):
     """Contiguous split of the image list (infer.py:151-169 forms the list; ranks take slices)."""
     base, rem = divmod(n_items, world)

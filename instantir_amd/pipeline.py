@@ -12,6 +12,9 @@ Observable deviations, all documented in SURVEY.md Appendix C and DESIGN.md:
   Q3  preview latents are copied to the host only when `save_preview_row=True`.
   Q5  `multistep_restore=True` raises NotImplementedError (unusable with the shipped scheduler).
   Q8/Q13  Resampler / embeddings hoisted out of the step.
+  Q15 the reference defaults `ip_adapter_image` to `[image]` BEFORE `check_inputs` (:1278-1279), so passing
+      `ip_adapter_image_embeds` always trips its own "provide either ... or ..." check (:850-853); here the default is
+      applied only when no embeds are given, so the embeds path (the parity hook) is usable.
 Latents are carried in fp32 between steps (the reference carries fp16); UNet inputs are fp16.
 """
 from __future__ import annotations
@@ -389,17 +392,27 @@ class InstantIRPipeline:
                 kwargs.get("negative_prompt_ids"), kwargs.get("negative_prompt_ids_2"), do_cfg, clip_skip)
             if negative_prompt_embeds is None:
                 negative_prompt_embeds, negative_pooled_prompt_embeds = ne, npool
-        B = prompt_embeds.shape[0] * num_images_per_prompt
+        nipp = int(num_images_per_prompt or 1)
+        pb = prompt_embeds.shape[0]                                                # `batch_size` of :1304-1315
         n_img = 1 if hasattr(image, "size") and not torch.is_tensor(image) and not isinstance(image, (list, tuple)) else len(image)
-        assert B == n_img or n_img == 1                                           # :1316-1319
+        assert pb == n_img or n_img == 1                                          # :1310-1315
+        if ip_adapter_image is None and ip_adapter_image_embeds is None:           # :1278-1279 (see Q15 in the header)
+            ip_adapter_image = image
+        if nipp > 1:            # diffusers encode_prompt: embeds.repeat(1, n, 1).view(bs * n, ...) == repeat_interleave
+            prompt_embeds = prompt_embeds.repeat_interleave(nipp, 0)
+            pooled_prompt_embeds = pooled_prompt_embeds.repeat_interleave(nipp, 0)
+            if negative_prompt_embeds is not None:
+                negative_prompt_embeds = negative_prompt_embeds.repeat_interleave(nipp, 0)
+                negative_pooled_prompt_embeds = negative_pooled_prompt_embeds.repeat_interleave(nipp, 0)
+        B = pb * nipp
         image = self._prepare_image(image)
         if image.shape[1] != 4:                                                        # :1369-1379
             if self.vae is None:
                 raise NotImplementedError("pixel-space `image` needs a VAE; pass the LQ latent (B,4,h,w)")
             image = self.vae.encode_to_latent(image, eps=kwargs.get("vae_noise"), generator=None)
         lq = image.to(dev, torch.float32)
-        if lq.shape[0] == 1 and B > 1:
-            lq = lq.repeat(B, 1, 1, 1)
+        # prepare_image :919-925: one image serves the whole batch, otherwise each image is repeated per prompt copy
+        lq = lq.repeat(B, 1, 1, 1) if lq.shape[0] == 1 else lq.repeat_interleave(nipp, 0)
         lq = lq.contiguous()
         Hl, Wl = lq.shape[2], lq.shape[3]
         height, width = Hl * self.vae_scale_factor, Wl * self.vae_scale_factor
@@ -430,18 +443,30 @@ class InstantIRPipeline:
             time_ids = torch.tensor([neg_ids, ids], dtype=torch.float32).repeat(B, 1)
         else:
             time_ids = torch.tensor([ids], dtype=torch.float32).repeat(R, 1)
-        if ip_adapter_image_embeds is None:                                         # :1350-1357
-            if ip_adapter_image is None:
-                raise ValueError("InstantIR conditions on the LQ image: pass `ip_adapter_image` or `ip_adapter_image_embeds`")
-            ip_adapter_image_embeds = self.prepare_ip_adapter_image_embeds(ip_adapter_image, do_cfg)
-        img = ip_adapter_image_embeds[0]
-        if do_cfg:                                                                  # :709-722
-            neg, pos = img.chunk(2)
-            img = torch.cat([neg.repeat(num_images_per_prompt, *([1] * (neg.dim() - 1))),
-                             pos.repeat(num_images_per_prompt, *([1] * (pos.dim() - 1)))])
+        if ip_adapter_image_embeds is None:                                         # :1350-1357, :672-707
+            f, z = self.encode_image(ip_adapter_image)                             # (Bimg, S, E) features, zero-image features
+            reps = max(B // f.shape[0], 1)                                         # torch.stack([e] * (B // e.shape[0]), dim=0)
+            f, z = torch.stack([f] * reps, 0), torch.stack([z] * reps, 0)
+            img = torch.cat([z, f]) if do_cfg else f
+        else:
+            img = ip_adapter_image_embeds[0]
+            if do_cfg:                                                              # :709-722
+                neg, pos = img.chunk(2)
+                img = torch.cat([neg.repeat(nipp, *([1] * (neg.dim() - 1))), pos.repeat(nipp, *([1] * (pos.dim() - 1)))])
+            else:
+                img = img.repeat(nipp, *([1] * (img.dim() - 1)))
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        n_rows = img.shape[0] * img.shape[1]
+        if n_rows != R:
+            raise ValueError(f"image embeds give {n_rows} rows, the batch has {R} (prompts {pb} x images-per-prompt {nipp}"
+                             f"{' x 2 (CFG)' if do_cfg else ''})")
 
         # -- timetable and gates (:1385, :1415-1425)
-        self.scheduler.set_timesteps(num_inference_steps, device=None, **({"timesteps": timesteps} if timesteps else {}))
+        if timesteps is not None:                                                   # retrieve_timesteps, :195-237
+            self.scheduler.set_timesteps(timesteps=list(timesteps), device=None)
+        else:
+            self.scheduler.set_timesteps(num_inference_steps, device=None)
         ts = [int(t) for t in self.scheduler.timesteps]
         n = len(ts)
         keep, previewing = [], []
@@ -482,30 +507,44 @@ class InstantIRPipeline:
                             guidance_rescale=guidance_rescale)
         preview_row = []
         preview_factor = torch.ones(B)
+        compound = None            # per-image scale the Aggregator's (persistent, raw) outputs currently carry
+        pv = None                  # positive half of `preview_latent`: what conditioned the Aggregator last (:1545-1582)
+        if adastep_restore and not do_cfg:
+            raise ValueError("adastep_restore slices preview_latent[B:], which is empty without classifier-free guidance "
+                             "(pipelines/sdxl_instantir.py:1638; SURVEY.md Appendix C Q6)")
         for i, t in enumerate(ts):
             scale_rows = torch.clamp(preview_factor, 0.0, ccs[i]) * keep[i]            # :1538-1540
             use_agg = bool((scale_rows > 0.1).sum().item() > 0)                      # :1542
-            mode = "unet"
             if use_agg:
                 mode = "preview" if (previewing[i] > 0 and st_prev is not None and previewer_scheduler is not None) else "agg"
                 if previewing[i] > 0 and (st_prev is None or previewer_scheduler is None):
                     raise RuntimeError("previewing requested but no previewer: call prepare_previewers(...) and pass "
                                        "previewer_scheduler=LCMSingleStepScheduler")
-            elif i == 0:
+                compound = scale_rows.clone()
+            elif compound is None:
                 raise RuntimeError("control_guidance_start > 0 leaves no aggregator residuals for step 0 "
                                    "(the reference fails with NameError here, SURVEY.md Appendix C Q2)")
+            else:
+                # :1602-1603 run unconditionally: the PREVIOUS step's already scaled residuals are scaled again (Q2).
+                # Zero everywhere (the creative phase, keep = 0) -> the adds are skipped, which is the same result.
+                compound = compound * scale_rows
+                mode = "unet_res" if bool((compound != 0).any()) else "unet"
             noise = None
             if step_noises is not None:
                 noise = step_noises[i]
-            x0 = loop.step(mode, t, x, scale_rows.repeat(rep), guidance_scale, eta, noise, generator,
-                           want_x0=adastep_restore, want_preview=save_preview_row or adastep_restore)
-            if mode == "preview" and save_preview_row:
-                preview_row.append(loop.preview_f32[B * (rep - 1):].clone().cpu())
+            x0 = loop.step(mode, t, x, (compound if mode != "unet" else scale_rows).repeat(rep), guidance_scale, eta, noise,
+                           generator, want_x0=adastep_restore, want_preview=save_preview_row or adastep_restore)
+            if mode == "preview":
+                pv = loop.preview_f32[B * (rep - 1):]
+                if save_preview_row:
+                    preview_row.append(pv.clone().cpu())
+            elif mode == "agg":
+                pv = reference_latents.to(dev, torch.float32) if reference_latents is not None else lq     # :1579-1582
             if adastep_restore:                                                    # :1636-1644
-                pv = loop.preview_f32[B * (rep - 1):].float() if mode == "preview" else lq
+                pv = pv.float().clone()
                 pred_x0_l2 = (pv - x0).pow(2).sum(dim=(1, 2, 3))
                 prev_l2 = (pv - loop.previewer_mean).pow(2).sum(dim=(1, 2, 3))
-                loop.previewer_mean = pv.clone()
+                loop.previewer_mean = pv
                 preview_factor = (pred_x0_l2 / prev_l2).cpu()
             if callback_on_step_end is not None:
                 cb = callback_on_step_end(self, i, t, {"latents": x})
@@ -516,7 +555,7 @@ class InstantIRPipeline:
         else:
             if self.vae is None:
                 raise NotImplementedError("output_type other than 'latent' needs a VAE attached to the pipeline")
-            image_out = self.vae.decode_latent(latents_out, output_type)
+            image_out = self.vae.decode_latent(latents_out, output_type)          # tiles when `vae.enable_tiling()` is on
         if save_preview_row and self.vae is not None and output_type != "latent":     # :1706-1729 (decoded independently, Q4)
             preview_row = [self.vae.decode_latent(pl, output_type) for pl in preview_row]
         if not return_dict:
@@ -569,6 +608,10 @@ class _DenoiseLoop:
         p, B, rep = self.p, self.B, self.rep
         ops.pack_latent(self.x_in, self.lat16, rep=rep)                      # cat([latents]*2), :1503
         down = mid = None
+        if mode == "unet_res":       # stale residuals of the last Aggregator pass, re-scaled (see __call__)
+            eps = p._unet.forward(self.lat16, self.t_dev, self.st, p._agg._out, p._agg._out_mid, self.res_scale)
+            self._sched(eps, use_noise, want_x0)
+            return
         if mode != "unet" and p.overlap_streams:
             # The main UNet's encoder half does not depend on the previewer / Aggregator: run it on a side
             # stream so its (CU-underfilling) launches overlap theirs; join before the residual adds.
@@ -579,11 +622,7 @@ class _DenoiseLoop:
             fork.record(main)
             self.side.wait_event(fork)
             with torch.cuda.stream(self.side):
-                # no weight prefetch here: the encoder is the hidden branch, and forking a third stream off a
-                # side stream inside a capture crashed hipStreamEndCapture on ROCm 7.2 for some graph shapes
-                pf, p._unet.prefetch = p._unet.prefetch, False
                 enc = p._unet.encode(self.lat16, self.t_dev, self.st)
-                p._unet.prefetch = pf
                 join.record(self.side)
             if mode == "preview":
                 eps1 = p._unet_prev.forward(self.lat16, self.t_dev, self.st_prev)

@@ -35,6 +35,9 @@ class HipVAE:
         self.has_decoder = "decoder.conv_in.weight" in sd
         self.has_encoder = "encoder.conv_in.weight" in sd
         self.tile_sample_size = 1024         # AutoencoderKL config.sample_size (autoencoder_kl.py:117-124)
+        self.tile_overlap_factor = 0.25      # autoencoder_kl.py:124
+        self.use_tiling = False              # `vae.enable_tiling()` (autoencoder_kl.py:130-143)
+        self.dtype_name = "fp16"
         t = lambda n: sd[n].to(device=self.device, dtype=F16)
         for name in sd:
             if not name.endswith(".weight"):
@@ -62,6 +65,17 @@ class HipVAE:
             else:
                 self.w[p + ".g"] = w.contiguous()
                 self.w[p + ".b"] = t(p + ".bias").contiguous()
+
+    def enable_tiling(self, use_tiling: bool = True):
+        """autoencoder_kl.py:130-136: decode latents larger than `tile_sample_size / 8` per side tile by tile."""
+        self.use_tiling = use_tiling
+
+    def disable_tiling(self):
+        self.enable_tiling(False)
+
+    @property
+    def tile_latent_min_size(self):
+        return self.tile_sample_size // 8       # sample_size / 2^(len(block_out_channels) - 1), autoencoder_kl.py:123
 
     # ---- blocks -----------------------------------------------------------------------------------
     def _resnet(self, path, x, R, H, W):
@@ -194,11 +208,17 @@ class HipVAE:
             out_rows.append(torch.cat(parts, dim=3))
         return torch.cat(out_rows, dim=2)
 
-    def decode_latent(self, latents: torch.Tensor, output_type: str = "pt", tiled: bool = False):
+    def decode_latent(self, latents: torch.Tensor, output_type: str = "pt", tiled=None):
         """pipelines/sdxl_instantir.py:1689-1704: latents / scaling_factor -> decode -> postprocess
-        (VaeImageProcessor: (x / 2 + 0.5).clamp(0, 1); 'pt' tensor, 'np' NHWC array, 'pil' images)."""
+        (VaeImageProcessor: (x / 2 + 0.5).clamp(0, 1); 'pt' tensor, 'np' NHWC array, 'pil' images).  Tiled when
+        `enable_tiling()` is on (or `tiled=True`) and a latent side exceeds the tile (autoencoder_kl.py:270-272)."""
         z = latents.to(self.device, torch.float32) / self.cfg.scaling_factor
-        img = self.decode_tiled(z, self.tile_sample_size) if tiled and max(z.shape[2:]) > self.tile_sample_size // 8 else self.decode(z)
+        tiled = self.use_tiling if tiled is None else tiled
+        big = z.shape[-1] > self.tile_latent_min_size or z.shape[-2] > self.tile_latent_min_size
+        img = self.decode_tiled(z, self.tile_sample_size, self.tile_overlap_factor) if tiled and big else self.decode(z)
+        if not torch.isfinite(img).all():
+            raise FloatingPointError("VAE decode produced non-finite pixels (activation overflow): this build stores VAE "
+                                     f"activations as {self.dtype_name}; see DESIGN.md section 7")
         img = (img / 2 + 0.5).clamp(0, 1)
         if output_type == "pt":
             return img

@@ -162,17 +162,38 @@ def resnet(P, path, x, temb, groups, lora=None, eps=1e-5):
     return x + h
 
 
+def attn_cross(P, path, x, ctx, heads, lora=None):
+    """AttnProcessor2_0.__call__ with encoder_hidden_states (attention_processor.py:337-414): the plain
+    SDXL cross-attention of module/min_sdxl.py:550-554 (no IP branch)."""
+    q = linear(P, path + ".to_q", x, lora)
+    k = linear(P, path + ".to_k", ctx, lora)
+    v = linear(P, path + ".to_v", ctx, lora)
+    return linear(P, path + ".to_out.0", sdpa(q, k, v, heads), lora)
+
+
+def geglu(P, path, x, lora=None):
+    """GEGLU, module/min_sdxl.py:502-510: x1 * gelu(x2), exact-erf GELU."""
+    a, g = linear(P, path + ".proj", x, lora).chunk(2, dim=-1)
+    return a * F.gelu(g)
+
+
+def feed_forward(P, path, x, lora=None):
+    """FeedForward, module/min_sdxl.py:513-528: GEGLU -> Dropout(0) -> Linear."""
+    return linear(P, path + ".net.2", geglu(P, path + ".net.0", x, lora), lora)
+
+
 def transformer_block(P, path, x, ctx, ip_tokens, temb, heads, lora=None):
-    """BasicTransformerBlock, module/min_sdxl.py:531-562; attn2 skipped when absent
-    (Aggregator after remove_attn2, pipelines/sdxl_instantir.py:165-177)."""
+    """BasicTransformerBlock, module/min_sdxl.py:531-562.  attn2 is skipped when absent (Aggregator after
+    remove_attn2, pipelines/sdxl_instantir.py:165-177), is the TA-IP processor when its weights are present
+    (module/ip_adapter/attention_processor.py:1093-1207) and plain cross-attention otherwise (stock SDXL)."""
     x = attn_self(P, path + ".attn1", layer_norm(P, path + ".norm1", x), heads, lora) + x
     if (path + ".attn2.to_q.weight") in P:
-        x = attn_ta_ip(P, path + ".attn2", layer_norm(P, path + ".norm2", x), ctx, ip_tokens, temb, heads, lora) + x
-    h = layer_norm(P, path + ".norm3", x)
-    h = linear(P, path + ".ff.net.0.proj", h, lora)
-    a, g = h.chunk(2, dim=-1)                                   # GEGLU, min_sdxl.py:502-510
-    h = linear(P, path + ".ff.net.2", a * F.gelu(g), lora)
-    return h + x
+        h = layer_norm(P, path + ".norm2", x)
+        if (path + ".attn2.processor.to_k_ip.weight") in P:
+            x = attn_ta_ip(P, path + ".attn2", h, ctx, ip_tokens, temb, heads, lora) + x
+        else:
+            x = attn_cross(P, path + ".attn2", h, ctx, heads, lora) + x
+    return feed_forward(P, path + ".ff", layer_norm(P, path + ".norm3", x), lora) + x
 
 
 def transformer2d(P, path, x, depth, ctx, ip_tokens, temb, heads, groups, lora=None):
@@ -201,31 +222,56 @@ def time_embedding(P, cfg, t, text_embeds, time_ids, lora=None):
     return e + a
 
 
+def down_block(P, path, x, emb, ctx, ip_tokens, n_res, depth, heads, groups, has_down, lora=None):
+    """DownBlock2D / CrossAttnDownBlock2D, module/min_sdxl.py:621-679: returns (x, [outputs])."""
+    outs = []
+    for j in range(n_res):
+        x = resnet(P, f"{path}.resnets.{j}", x, emb, groups, lora)
+        if depth > 0:
+            x = transformer2d(P, f"{path}.attentions.{j}", x, depth, ctx, ip_tokens, emb, heads, groups, lora)
+        outs.append(x)
+    if has_down:
+        x = conv2d(P, f"{path}.downsamplers.0.conv", x, stride=2, padding=1, lora=lora)   # Downsample2D :598-606
+        outs.append(x)
+    return x, outs
+
+
+def up_block(P, path, x, skips, emb, ctx, ip_tokens, depth, heads, groups, has_up, lora=None):
+    """CrossAttnUpBlock2D / UpBlock2D, module/min_sdxl.py:682-761: `skips` is consumed from its END
+    (res_hidden_states_tuple[-1] first), one per resnet."""
+    skips = list(skips)
+    for j in range(len(skips)):
+        x = torch.cat([x, skips.pop()], dim=1)                           # min_sdxl.py:706-717
+        x = resnet(P, f"{path}.resnets.{j}", x, emb, groups, lora)
+        if depth > 0:
+            x = transformer2d(P, f"{path}.attentions.{j}", x, depth, ctx, ip_tokens, emb, heads, groups, lora)
+    if has_up:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")          # Upsample2D, min_sdxl.py:609-618
+        x = conv2d(P, f"{path}.upsamplers.0.conv", x, lora=lora)
+    return x
+
+
+def mid_block(P, path, x, emb, ctx, ip_tokens, depth, heads, groups, lora=None):
+    """UNetMidBlock2DCrossAttn, module/min_sdxl.py:764-786."""
+    x = resnet(P, path + ".resnets.0", x, emb, groups, lora)
+    x = transformer2d(P, path + ".attentions.0", x, depth, ctx, ip_tokens, emb, heads, groups, lora)
+    return resnet(P, path + ".resnets.1", x, emb, groups, lora)
+
+
 def _down_blocks(P, cfg, x, emb, ctx, ip_tokens, lora):
-    """conv_in output -> list of skip tensors (module/min_sdxl.py:620-677, 869-889)."""
+    """conv_in output -> list of skip tensors (module/min_sdxl.py:869-889)."""
     skips = [x]
     nb = len(cfg.block_out_channels)
     for i, c in enumerate(cfg.block_out_channels):
-        heads = c // cfg.head_dim
-        for j in range(cfg.layers_per_block):
-            x = resnet(P, f"down_blocks.{i}.resnets.{j}", x, emb, cfg.norm_groups, lora)
-            if cfg.transformer_depth[i] > 0:
-                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, cfg.transformer_depth[i], ctx, ip_tokens,
-                                  emb, heads, cfg.norm_groups, lora)
-            skips.append(x)
-        if i < nb - 1:
-            x = conv2d(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, padding=1, lora=lora)
-            skips.append(x)
+        x, outs = down_block(P, f"down_blocks.{i}", x, emb, ctx, ip_tokens, cfg.layers_per_block,
+                             cfg.transformer_depth[i], c // cfg.head_dim, cfg.norm_groups, i < nb - 1, lora)
+        skips += outs
     return x, skips
 
 
 def _mid_block(P, cfg, x, emb, ctx, ip_tokens, lora):
-    """UNetMidBlock2DCrossAttn, module/min_sdxl.py:757-779."""
     c = cfg.block_out_channels[-1]
-    x = resnet(P, "mid_block.resnets.0", x, emb, cfg.norm_groups, lora)
-    x = transformer2d(P, "mid_block.attentions.0", x, cfg.mid_depth, ctx, ip_tokens, emb, c // cfg.head_dim,
-                      cfg.norm_groups, lora)
-    return resnet(P, "mid_block.resnets.1", x, emb, cfg.norm_groups, lora)
+    return mid_block(P, "mid_block", x, emb, ctx, ip_tokens, cfg.mid_depth, c // cfg.head_dim, cfg.norm_groups, lora)
 
 
 def unet_forward(P, cfg, sample, t, ctx, text_embeds, time_ids, ip_tokens, down_res=None, mid_res=None, lora=None,
@@ -249,17 +295,12 @@ def unet_forward(P, cfg, sample, t, ctx, text_embeds, time_ids, ip_tokens, down_
         x = x + mid_res
     rev = list(reversed(cfg.block_out_channels))
     nb = len(rev)
+    n = cfg.layers_per_block + 1
     for i, c in enumerate(rev):
         depth = list(reversed(cfg.transformer_depth))[i]
-        for j in range(cfg.layers_per_block + 1):
-            x = torch.cat([x, skips.pop()], dim=1)                       # min_sdxl.py:706-717
-            x = resnet(P, f"up_blocks.{i}.resnets.{j}", x, emb, cfg.norm_groups, lora)
-            if depth > 0:
-                x = transformer2d(P, f"up_blocks.{i}.attentions.{j}", x, depth, ctx, ip_tokens, emb,
-                                  c // cfg.head_dim, cfg.norm_groups, lora)
-        if i < nb - 1:
-            x = F.interpolate(x, scale_factor=2.0, mode="nearest")      # min_sdxl.py:609-618
-            x = conv2d(P, f"up_blocks.{i}.upsamplers.0.conv", x, lora=lora)
+        take, skips = skips[-n:], skips[:-n]
+        x = up_block(P, f"up_blocks.{i}", x, take, emb, ctx, ip_tokens, depth, c // cfg.head_dim, cfg.norm_groups,
+                     i < nb - 1, lora)
     x = F.silu(group_norm(P, "conv_norm_out", x, cfg.norm_groups, 1e-5))
     return conv2d(P, "conv_out", x)
 

@@ -72,14 +72,15 @@ def add_noise(alphas_cumprod, original, noise, timesteps):
 
 
 def ddpm_step(alphas_cumprod, model_output, t, sample, num_inference_steps, noise=None,
-              num_train_timesteps=1000):
+              num_train_timesteps=1000, prev_t=None):
     """DDPM ancestral step, epsilon prediction, variance 'fixed_small', no clipping.
 
     Returns (prev_sample, pred_original_sample).  `noise` is the N(0,1) draw the reference takes
     from `generator` iff t > 0; pass it explicitly.
     """
     t = int(t)
-    prev_t = t - num_train_timesteps // num_inference_steps
+    if prev_t is None:          # custom timetables (diffusers DDPM `previous_timestep`): the next entry of the list, -1 at the end
+        prev_t = t - num_train_timesteps // num_inference_steps
     a_t = alphas_cumprod[t]
     a_prev = alphas_cumprod[prev_t] if prev_t >= 0 else torch.tensor(1.0)
     b_t = 1 - a_t

@@ -9,9 +9,13 @@ pytestmark = pytest.mark.gpu
 
 
 def psnr(got, want):
+    import inspect
+    from conftest import record_psnr
     mse = ((got - want) ** 2).mean().item()
     peak = want.abs().max().item()
-    return 10 * math.log10(peak * peak / max(mse, 1e-30))
+    v = 10 * math.log10(peak * peak / max(mse, 1e-30))
+    record_psnr("engine." + inspect.stack()[1].function, v)
+    return v
 
 
 @pytest.fixture(scope="module")
@@ -93,7 +97,7 @@ def test_unet_forward_matches_oracle(env, use_lora):
     torch.cuda.synchronize()
     got = _to_nchw(eps, R, H, H)
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p > 45, p
+    assert torch.isfinite(got).all() and p >= 50, p
 
 
 def test_aggregator_matches_oracle(env):
@@ -111,5 +115,5 @@ def test_aggregator_matches_oracle(env):
     for k, (d, w_) in enumerate(zip(down, wd)):
         h = w_.shape[2]
         p = psnr(_to_nchw(d, R, h, w_.shape[3]), w_)
-        assert p > 45, (k, p)
-    assert psnr(_to_nchw(mid, R, wm.shape[2], wm.shape[3]), wm) > 45
+        assert p >= 50, (k, p)
+    assert psnr(_to_nchw(mid, R, wm.shape[2], wm.shape[3]), wm) >= 50

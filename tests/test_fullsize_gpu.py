@@ -1,6 +1,8 @@
-"""GPU parity at FULL SDXL / InstantIR shapes -- BASELINE.json configs[0]: single 512x512 input, 4-step DDIM,
-cfg = 1.0 (no CFG doubling), CPU fp32 oracle vs the HIP path, seeded synthetic weights (4.4 B parameters).
-The north-star tolerance is latent PSNR >= 50 dB at fp16.  Takes ~1-2 minutes (CPU oracle on the box's cores)."""
+"""GPU parity at FULL SDXL / InstantIR shapes against the CPU fp32 oracle, seeded synthetic weights (4.4 B parameters):
+BASELINE.json configs[0] (single 512x512 input, 4-step DDIM, cfg = 1.0, no CFG doubling), the CFG-doubled batch at
+512 px, and configs[1]'s own geometry -- 1024x1024, cfg 7.0 (T = 4096 / 8192 token attention, the 1024^2 tile-chooser
+picks) -- for one step (the oracle needs ~75 s per CFG step at that size on the box's 16 cores; `tools/parity_fullsize.py`
+runs more steps).  The north-star tolerance is latent PSNR >= 50 dB at fp16."""
 import math
 import os
 
@@ -21,9 +23,9 @@ def _host_cores():
     return n
 
 
-@pytest.mark.parametrize("guidance,steps", [(1.0, 4), (7.0, 3)])
-def test_config0_512px_full_sdxl_shapes(guidance, steps):
-    """(1.0, 4) is BASELINE configs[0]; (7.0, 3) adds the CFG-doubled batch (2 rows) of configs[1] at 512 px."""
+@pytest.mark.parametrize("size,guidance,steps", [(512, 1.0, 4), (512, 7.0, 3), (1024, 7.0, 1)])
+def test_full_sdxl_shapes(size, guidance, steps):
+    """(512, 1.0, 4) is BASELINE configs[0]; (512, 7.0, 3) adds the CFG-doubled batch; (1024, 7.0, 1) is configs[1]'s geometry."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from instantir_amd import lib, weights as W
@@ -38,7 +40,7 @@ def test_config0_512px_full_sdxl_shapes(guidance, steps):
     sda = W.synth_state_dict(W.aggregator_specs(cfg), 1235, device=dev)
     lora = W.synth_state_dict(W.lora_specs(cfg), 1236, device=dev)
     g = torch.Generator().manual_seed(42)
-    B, H = 1, 64
+    B, H = 1, size // 8
     lq = torch.randn(B, 4, H, H, generator=g) * 0.8
     pe = torch.randn(B, 77, 2048, generator=g).half().float()
     pooled = torch.randn(B, 1280, generator=g).half().float()
@@ -68,5 +70,7 @@ def test_config0_512px_full_sdxl_shapes(guidance, steps):
                           init_noise=noise, num_inference_steps=steps, guidance_scale=guidance, sampler="ddim")
     mse = ((got - want) ** 2).mean().item()
     p = 10 * math.log10(want.abs().max().item() ** 2 / max(mse, 1e-30))
-    print(f"full-shape 512px cfg={guidance} steps={steps}: latent PSNR vs CPU fp32 oracle {p:.1f} dB")
+    print(f"full-shape {size}px cfg={guidance} steps={steps}: latent PSNR vs CPU fp32 oracle {p:.1f} dB")
+    from conftest import record_psnr
+    record_psnr(f"fullsize.{size}px.cfg{guidance}.steps{steps}", p)
     assert p >= 50.0, p

@@ -9,10 +9,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+BAR = 50.0     # BASELINE.json north_star: latent PSNR >= 50 dB against the reference path at fp16
+
+
 def psnr(got, want):
+    import inspect
+    from conftest import record_psnr
     mse = ((got - want) ** 2).mean().item()
     peak = want.abs().max().item()
-    return 10 * math.log10(peak * peak / max(mse, 1e-30))
+    v = 10 * math.log10(peak * peak / max(mse, 1e-30))
+    record_psnr("pipeline." + inspect.stack()[1].function, v)
+    return v
 
 
 @pytest.fixture(scope="module")
@@ -78,7 +85,7 @@ def test_ddim_cfg_loop(env, graphs):
     pipe.use_graphs = graphs
     got = _call(pipe, inp, num_inference_steps=6, guidance_scale=7.0)
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p >= 40, p
+    assert torch.isfinite(got).all() and p >= BAR, p
 
 
 def test_ddpm_phases_loop(env):
@@ -90,7 +97,7 @@ def test_ddpm_phases_loop(env):
     pipe = _pipe(cfg, sd, sda, lora, DDPMScheduler())
     got = _call(pipe, inp, step_noises=inp["noises"], **kw)
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p >= 40, p
+    assert torch.isfinite(got).all() and p >= BAR, p
 
 
 def test_guidance_rescale_loop(env):
@@ -103,7 +110,7 @@ def test_guidance_rescale_loop(env):
     pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
     got = _call(pipe, inp, **kw)
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p >= 40, p
+    assert torch.isfinite(got).all() and p >= BAR, p
     assert psnr(got, plain) < p - 6          # the rescale is live: clearly closer to the rescaled oracle than to the plain one
 
 
@@ -118,7 +125,7 @@ def test_negative_size_conditioning(env):
     pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
     got = _call(pipe, inp, negative_original_size=neg[:2], negative_crops_coords_top_left=neg[2:4], negative_target_size=neg[4:], **kw)
     p = psnr(got, want)
-    assert p >= 40 and psnr(got, plain) < p - 6, (p, psnr(got, plain))
+    assert p >= BAR and psnr(got, plain) < p - 6, (p, psnr(got, plain))
 
 
 def test_aggregator_from_unet_emits_zero_residuals(env):
@@ -136,7 +143,7 @@ def test_aggregator_from_unet_emits_zero_residuals(env):
     want = _oracle(cfg, sd, agg, lora, inp, num_inference_steps=2, guidance_scale=5.0, sampler="ddim")
     trained = _oracle(cfg, sd, sda, lora, inp, num_inference_steps=2, guidance_scale=5.0, sampler="ddim")
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p >= 40 and psnr(got, trained) < p - 6
+    assert torch.isfinite(got).all() and p >= BAR and psnr(got, trained) < p - 6
 
 
 def test_no_cfg_single_image(env):
@@ -160,7 +167,7 @@ def test_no_cfg_single_image(env):
                previewer_scheduler=LCMSingleStepScheduler.from_config(pipe.scheduler.config),
                init_noise=one["init_noise"]).images.float().cpu()
     p = psnr(got, want)
-    assert p >= 40, p
+    assert p >= BAR, p
 
 
 def test_single_step_previewer_restoration(env):
@@ -184,4 +191,102 @@ def test_single_step_previewer_restoration(env):
     eps = nets.unet_forward(P, cfg, x, 999, inp["pe"], inp["pooled"], tid, ip, lora=L)
     want = sched.lcm_step(acp, eps, 999, x)
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p >= 40, p
+    assert torch.isfinite(got).all() and p >= BAR, p
+
+
+def test_adastep_restore_with_reference_latents_and_a_gated_step(env):
+    """adastep_restore (pipelines/sdxl_instantir.py:1636-1644) with `reference_latents` (:1579-1580) and a per-step scale
+    list whose third entry (0.05) puts every row below the 0.1 gate (:1542): that step skips previewer + Aggregator and
+    re-scales the previous step's already scaled residuals (:1602-1603); the next step's factor is pred / 0 = inf,
+    clamped back to the scale.  Checked against the oracle loop, which restates those statements one by one."""
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    g = torch.Generator().manual_seed(7)
+    ref = torch.randn(inp["B"], 4, inp["H"], inp["H"], generator=g) * 0.8
+    kw = dict(num_inference_steps=5, guidance_scale=5.0, adastep_restore=True, reference_latents=ref, preview_end=0.4,
+              controlnet_conditioning_scale=[1.0, 1.0, 0.05, 1.0, 1.0])
+    trace = {}
+    want = _oracle(cfg, sd, sda, lora, inp, sampler="ddim", trace=trace, **kw)
+    modes = [bool((c > 0.1).any()) for c in trace["cond_scale"]]
+    assert modes == [True, True, False, True, True]                         # the gated step is really exercised
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    got = _call(pipe, inp, **kw)
+    plain = _oracle(cfg, sd, sda, lora, inp, sampler="ddim", **{**kw, "adastep_restore": False})
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p >= BAR and psnr(got, plain) < p - 6, (p, psnr(got, plain))
+
+
+def test_adastep_needs_cfg(env):
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    with pytest.raises(ValueError):
+        _call(pipe, inp, num_inference_steps=2, guidance_scale=1.0, adastep_restore=True)
+
+
+def test_denoising_end_custom_timesteps_and_callback(env):
+    """`denoising_end` (:1470-1483) cuts the timetable while the gates keep the full step count; `timesteps=` (:195-237)
+    hands the DDPM scheduler a custom descending list (previous timestep = next list entry); `callback_on_step_end`
+    (:1651-1659) may replace the latents."""
+    from instantir_amd.schedulers import DDIMScheduler, DDPMScheduler
+    cfg, sd, sda, lora, inp = env
+    kw = dict(num_inference_steps=6, guidance_scale=5.0, denoising_end=0.5)
+    want = _oracle(cfg, sd, sda, lora, inp, sampler="ddim", **kw)
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    seen = []
+
+    def cb(p_, i, t, kwargs):
+        seen.append((i, int(t)))
+        return {"latents": kwargs["latents"]}
+
+    got = _call(pipe, inp, callback_on_step_end=cb, **kw)
+    assert seen == [(0, 831), (1, 665)]                  # N = 6 timetable 831, 665, 499, ...: cutoff 500 keeps two steps
+    p = psnr(got, want)
+    assert p >= BAR, p
+    tlist = [901, 601, 301, 1]
+    want = _oracle(cfg, sd, sda, lora, inp, sampler="ddpm", timesteps=tlist, guidance_scale=5.0, step_noises=inp["noises"])
+    pipe2 = _pipe(cfg, sd, sda, lora, DDPMScheduler())
+    got = _call(pipe2, inp, timesteps=tlist, guidance_scale=5.0, step_noises=inp["noises"])
+    p = psnr(got, want)
+    assert p >= BAR, p
+
+
+def test_num_images_per_prompt(env):
+    """num_images_per_prompt = 2 with ONE prompt / image: embeds repeat per prompt copy (diffusers encode_prompt), the LQ
+    latent repeats over the batch (prepare_image :919-925), IP embeds repeat on dim 0 (:709-722).  Rows are independent, so
+    each output row must equal the single-image run given the same noise row."""
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    one = {k: (v[:1] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == inp["B"] else v) for k, v in inp.items()}
+    one["img"] = inp["img"][:, :1]
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    noise2 = inp["init_noise"]                                             # (2,4,H,H): one row per generated image
+    both = _call(pipe, {**one, "init_noise": noise2}, num_inference_steps=2, guidance_scale=5.0, num_images_per_prompt=2)
+    assert both.shape[0] == 2
+    for r in range(2):
+        single = _call(pipe, {**one, "init_noise": noise2[r:r + 1]}, num_inference_steps=2, guidance_scale=5.0)
+        assert psnr(both[r:r + 1], single) >= 70            # same kernels, same inputs: only batch-size dependent tiling differs
+
+
+def test_ip_adapter_image_defaults_to_image_and_preview_row(env):
+    """`pipe(prompt_embeds=..., image=lq)` without ip_adapter_image (infer.py:211-222): it defaults to the LQ image
+    (:1278-1279) and goes through `encode_image`; with no image encoder attached that is a clear error, with one attached
+    the call runs.  `save_preview_row` (:1564-1567, :1706-1729) returns one preview per previewing step."""
+    from instantir_amd.schedulers import DDIMScheduler, LCMSingleStepScheduler
+    cfg, sd, sda, lora, inp = env
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    lcm = LCMSingleStepScheduler.from_config(pipe.scheduler.config)
+    base = dict(image=inp["lq"], prompt_embeds=inp["pe"], pooled_prompt_embeds=inp["pooled"], output_type="latent",
+                previewer_scheduler=lcm, init_noise=inp["init_noise"], num_inference_steps=3, guidance_scale=5.0)
+    with pytest.raises(NotImplementedError):
+        pipe(**base)
+
+    class _Enc:                                            # stands in for encoders.HipDinov2: (features, zero-image features)
+        def encode_image_pair(self, px):
+            return inp["img"][1].to(px.device if torch.is_tensor(px) else "cpu"), inp["img"][0]
+
+    pipe.image_encoder = _Enc()
+    out, row = pipe(**base, return_dict=False, save_preview_row=True, preview_end=0.7)
+    want = _call(pipe, inp, num_inference_steps=3, guidance_scale=5.0, preview_end=0.7)
+    assert psnr(out.float().cpu(), want) >= 70
+    assert len(row) == 2 and all(r.shape == inp["lq"].shape for r in row)     # steps 0 and 1 preview, step 2 does not
