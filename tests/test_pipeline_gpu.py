@@ -277,7 +277,7 @@ def test_ip_adapter_image_defaults_to_image_and_preview_row(env):
     pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
     lcm = LCMSingleStepScheduler.from_config(pipe.scheduler.config)
     base = dict(image=inp["lq"], prompt_embeds=inp["pe"], pooled_prompt_embeds=inp["pooled"], output_type="latent",
-                previewer_scheduler=lcm, init_noise=inp["init_noise"], num_inference_steps=3, guidance_scale=5.0)
+                negative_prompt_embeds=inp["npe"], negative_pooled_prompt_embeds=inp["npooled"], previewer_scheduler=lcm, init_noise=inp["init_noise"], num_inference_steps=3, guidance_scale=5.0)
     with pytest.raises(NotImplementedError):
         pipe(**base)
 
