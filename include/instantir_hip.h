@@ -114,6 +114,8 @@ typedef struct iir_attn_desc {
     float scale;                                    /* 1/sqrt(64) for SDPA                           */
     iir_attn_kv kv[2];
     int32_t causal;                                 /* != 0: key j is visible to query i only if j <= i */
+    int32_t q_prescaled;                            /* != 0: Q already holds q * scale * log2(e) (the caller folded the factor
+                                                     *   into the projection weights); the kernel then uses Q as it stands   */
 } iir_attn_desc;
 
 /* Replaces F.scaled_dot_product_attention at module/ip_adapter/attention_processor.py:394 (nseg=1)

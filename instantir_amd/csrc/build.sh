@@ -11,8 +11,9 @@ for f in gemm_conv norm; do
   pids+=($!)
 done
 # attention: keep MFMA accumulators in VGPRs (softmax reads/rescales them every tile; AGPR form costs
-# a v_accvgpr_read/write pair per touched element)
-hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 -c attention.hip -o build/attention.o &
+# a v_accvgpr_read/write pair per touched element).  -fno-honor-nans: the row maxima are fmaxf over MFMA outputs; with NaNs
+# honoured hipcc canonicalises every operand first (one extra v_max per score); -inf (masking) stays legal.
+hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans -c attention.hip -o build/attention.o &
 pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c pointwise.hip -o build/pointwise.o &
 pids+=($!)

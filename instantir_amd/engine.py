@@ -141,6 +141,11 @@ class _Net:
     def _t(self, sd, name):
         return sd[name].to(device=self.device, dtype=F16)
 
+    def _qw(self, sd, name):
+        """q-projection weight x (head_dim^-1/2 * log2 e), formed in fp32, stored fp16."""
+        f = ops.attn_q_factor(self.cfg.head_dim ** -0.5)
+        return (sd[name].to(device=self.device, dtype=torch.float32) * f).to(F16)
+
     def _pack_linear(self, sd, path, dst=None):
         dst = dst or path
         self.w[dst + ".w"] = self._t(sd, path + ".weight").contiguous()
@@ -174,12 +179,13 @@ class _Net:
             p = f"{path}.transformer_blocks.{k}"
             self._pack_norm(sd, p + ".norm1")
             # one projection for q | k | v: the V third is written transposed by the GEMM's epilogue (iir_gemm_desc.Ct)
-            self.w[p + ".attn1.qkv.w"] = torch.cat([self._t(sd, p + ".attn1.to_q.weight"), self._t(sd, p + ".attn1.to_k.weight"),
+            # (the softmax scale x log2 e is folded into the q rows: the attention kernel takes Q as it stands, `q_prescaled`)
+            self.w[p + ".attn1.qkv.w"] = torch.cat([self._qw(sd, p + ".attn1.to_q.weight"), self._t(sd, p + ".attn1.to_k.weight"),
                                                     self._t(sd, p + ".attn1.to_v.weight")], 0).contiguous()
             self._pack_linear(sd, p + ".attn1.to_out.0")
             if self.cross:
                 self._pack_norm(sd, p + ".norm2")
-                self._pack_linear(sd, p + ".attn2.to_q")
+                self.w[p + ".attn2.to_q.w"] = self._qw(sd, p + ".attn2.to_q.weight").contiguous()
                 self._pack_linear(sd, p + ".attn2.to_k")
                 self._pack_linear(sd, p + ".attn2.to_v")
                 self._pack_linear(sd, p + ".attn2.to_out.0")
@@ -362,7 +368,7 @@ class _Net:
             o.gemm(n, wqkv[:2 * C], qk, prefetch=self._pf(wqkv))
             o.gemm(wqkv[2 * C:], n, vt)                                                   # V^T = Wv . X^T (operands swapped)
         a = A.alloc(M, C)
-        o.attention(qk[:, :C], a, [(qk[:, C:], T, vt, T, T)], R, heads, T)
+        o.attention(qk[:, :C], a, [(qk[:, C:], T, vt, T, T)], R, heads, T, q_prescaled=True)
         o.gemm(a, w[p + ".attn1.to_out.0.w"], h, bias=w[p + ".attn1.to_out.0.b"], res=h,
                prefetch=self._pf(w[p + ".attn1.to_out.0.w"]))
         # -- decoupled cross-attention (TA_IPAttnProcessor2_0, attention_processor.py:1140-1195)
@@ -375,7 +381,7 @@ class _Net:
             kv = st["kv"][p]
             ipk, ipvt = kv["ipk"], kv["ipvt"]          # adaLN'd for this step by the batched launch in _embeddings
             o.attention(q, a, [(kv["tk"], cfg.text_len, kv["tvt"], kv["tpad"], cfg.text_len), (ipk, nip, ipvt, ipad, nip)],
-                        R, heads, T)
+                        R, heads, T, q_prescaled=True)
             o.gemm(a, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h,
                    prefetch=self._pf(w[p + ".attn2.to_out.0.w"]))
         # -- GEGLU feed-forward (module/min_sdxl.py:502-528)

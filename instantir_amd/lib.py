@@ -79,6 +79,7 @@ class AttnDesc(C.Structure):
         ("scale", C.c_float),
         ("kv", AttnKV * 2),
         ("causal", C.c_int32),
+        ("q_prescaled", C.c_int32),
     ]
 
 

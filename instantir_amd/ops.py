@@ -192,7 +192,16 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     return out
 
 
-def attention(q, o, kv, batch, heads, Tq, scale=0.125, causal=False):
+ATTN_LOG2E = 1.4426950408889634
+
+
+def attn_q_factor(scale=0.125):
+    """The factor a caller folds into its q-projection weights to pass `q_prescaled=True` (float32, as the kernel forms it)."""
+    import numpy as np
+    return float(np.float32(scale) * np.float32(ATTN_LOG2E))
+
+
+def attention(q, o, kv, batch, heads, Tq, scale=0.125, causal=False, q_prescaled=False):
     """q, o: 2-D views (batch*Tq, heads*64).  kv: list of 1-2 tuples (k2d, k_batch_rows, vt2d, vt_batch_stride, Tkv):
     k2d (batch*k_batch_rows, heads*64) view, vt2d (heads*64, cols) view with batch b starting at column b*vt_batch_stride."""
     _chk2d(q, "q"); _chk2d(o, "o")
@@ -201,6 +210,7 @@ def attention(q, o, kv, batch, heads, Tq, scale=0.125, causal=False):
     d.O, d.ldo, d.o_batch_stride = o.data_ptr(), o.stride(0), Tq * o.stride(0)
     d.batch, d.heads, d.Tq, d.nseg, d.scale = batch, heads, Tq, len(kv), scale
     d.causal = int(bool(causal))
+    d.q_prescaled = int(bool(q_prescaled))
     for i, (k, k_rows, vt, vbs, tkv) in enumerate(kv):
         _chk2d(k, "k"); _chk2d(vt, "vt")
         d.kv[i].K, d.kv[i].ldk, d.kv[i].k_batch_stride = k.data_ptr(), k.stride(0), k_rows * k.stride(0)
