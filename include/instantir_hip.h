@@ -38,6 +38,9 @@ extern "C" {
  * the kernel has 2*n_out rows where rows [16*b, 16*b+8) = V[8*b, 8*b+8) and
  * rows [16*b+8, 16*b+16) = G[8*b, 8*b+8).  (Host helper: instantir_amd.packing.pair_rows.) */
 
+#define IIR_DT_F16 0
+#define IIR_DT_BF16 1
+
 typedef struct iir_gemm_desc {
     const void* A; int64_t lda;    /* [M][K] activations, row stride lda                           */
     const void* W;                 /* [N][K] weights (torch nn.Linear layout), K contiguous        */
@@ -56,6 +59,11 @@ typedef struct iir_gemm_desc {
     void* Ct; int64_t ldct;        /* optional (PLAIN epilogue, no residual on those columns): output columns n >= tr_from */
     int32_t tr_from;               /*   are stored TRANSPOSED, Ct[(n - tr_from) * ldct + m] -- the V third of a fused       */
                                    /*   q|k|v projection lands as the V^T image iir_attention_d64_f16 consumes              */
+    int32_t dtype;                 /* IIR_DT_F16 (0) or IIR_DT_BF16 (1): element type of A, W, C, bias, rowbias, res.  The  */
+                                   /*   bf16 build serves the VAE, which the reference runs in fp32 because the SDXL VAE   */
+                                   /*   overflows fp16 (pipelines/sdxl_instantir.py:984-1001,1668-1674)                     */
+    int32_t c_f32;                 /* != 0: C is float [M][N] (ldc in floats, plain epilogue, out_scale only): the VAE     */
+                                   /*   mid-block attention scores stay fp32 through their softmax                          */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -94,6 +102,7 @@ typedef struct iir_conv_desc {
     int64_t prefetch_bytes;
     void* splitk_ws;               /* as in iir_gemm_desc (M = R*Ho*Wo, N = Cout)                  */
     int64_t splitk_ws_bytes;
+    int32_t dtype;                 /* IIR_DT_F16 / IIR_DT_BF16, as in iir_gemm_desc                */
 } iir_conv_desc;
 
 /* Replaces nn.Conv2d call sites: ResnetBlock2D module/min_sdxl.py:256-259,274 (+ the temb add :267 as
@@ -127,6 +136,11 @@ int iir_attention_d64_f16(const iir_attn_desc* a, void* stream);
 int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
                            int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
                            void* workspace, int64_t workspace_bytes, void* stream);
+/* the same for fp16 or bf16 tensors (X, Y, gamma, beta of type `dtype`): the VAE's GroupNorms (eps 1e-6,
+ * module/diffusers_vae/vae.py via unet_2d_ZeroSFT_blocks.py:2804-2874) run on bf16 activations */
+int iir_groupnorm_nhwc(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
+                       int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
+                       void* workspace, int64_t workspace_bytes, int32_t dtype, void* stream);
 int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups);
 
 /* nn.LayerNorm (module/min_sdxl.py:534-538; resampler.py:15,43-44,98) and AdaLayerNorm's
@@ -154,6 +168,10 @@ int iir_adaln_batch_f16(const iir_adaln_job* jobs_dev, int32_t njobs, int32_t ro
  * attention (1 head of dim 512, T = (H/8)*(W/8) tokens; torch.softmax inside F.scaled_dot_product_attention,
  * module/ip_adapter/attention_processor.py:394 as used by module/unet/unet_2d_ZeroSFT_blocks.py:776-790). */
 int iir_softmax_rows_f16(void* X, int64_t ld, int32_t rows, int32_t cols, void* stream);
+/* softmax over the columns of fp32 scores S[rows][cols] (cols % 4 == 0, <= 16384) written as fp16 / bf16 probabilities P:
+ * the VAE mid-block attention (Attention(heads=1), unet_2d_ZeroSFT_blocks.py:776-790) keeps its scores in fp32 through the
+ * softmax like the reference's upcast VAE (pipelines/sdxl_instantir.py:984-1001) */
+int iir_softmax_rows_f32(const float* S, int64_t lds, void* P, int64_t ldp, int32_t rows, int32_t cols, int32_t dtype, void* stream);
 
 /* Timesteps: module/min_sdxl.py:205-224.  out[r][col_off + v*dim + ...] = [cos | sin](vals[r][v] * w_k). */
 int iir_sinusoid_f16(const float* vals, int32_t n_vals, int32_t rows, int32_t dim, void* out, int64_t ldo,
@@ -170,6 +188,10 @@ int iir_copy_add_f16(const void* src, int64_t lds, void* dst, int64_t ldd, int64
 int iir_pack_latent(const float* x, int32_t B, int32_t C, int32_t HW, void* out, int64_t ldo, int32_t rep, float scale,
                     void* stream);
 int iir_unpack_latent(const void* in, int64_t ldi, int32_t R, int32_t C, int32_t HW, float* out, void* stream);
+/* the same with the 16-bit side as fp16 or bf16 (`dtype`): image / latent hand-over of the bf16 VAE */
+int iir_pack_latent_t(const float* x, int32_t B, int32_t C, int32_t HW, void* out, int64_t ldo, int32_t rep, float scale,
+                      int32_t dtype, void* stream);
+int iir_unpack_latent_t(const void* in, int64_t ldi, int32_t R, int32_t C, int32_t HW, float* out, int32_t dtype, void* stream);
 
 /* CFG + main scheduler step (pipelines/sdxl_instantir.py:1619-1633).  coef = device fp32[8]:
  * {guidance, sqrt(1-abar_t), sqrt(abar_t), k_x0, k_x, k_eps, k_noise, 0}; prev = k_x0*x0 + k_x*x + k_eps*eps

@@ -265,9 +265,15 @@ __device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const 
         }
     }
     // ---- tile maximum of the row (relative to the running maximum), both lane halves
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+    float mx, mxb;                                  // two independent v_max3 chains (latency, not count, is what a lone wave pays)
+    mx = fmaxf(sacc[0][0], sacc[0][1]);
+    mxb = fmaxf(sacc[1][0], sacc[1][1]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);       // v_max3_f32
+    for (int r = 2; r < 16; r += 2) {
+        mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[0][r + 1]);
+        mxb = fmaxf(fmaxf(mxb, sacc[1][r]), sacc[1][r + 1]);
+    }
+    mx = fmaxf(mx, mxb);
     {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -297,16 +303,16 @@ __device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const 
         for (int r = 0; r < 16; ++r) negm[r] = -m;
     }
     // ---- P = 2^S', row sums (this lane's half of the keys)
-    float lsum = 0.f;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};             // four independent partial sums
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(sacc[kb][r]);
             sacc[kb][r] = p;
-            lsum += p;
+            ls[r & 3] += p;
         }
-    l += lsum;
+    l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
     // ---- O^T += V^T . P^T : k-step (kb, sp).  The K rows of the tile were staged in the order that makes accumulator
     //      register 8*sp + j of lane half hh the score of key 32*kb + 16*sp + 8*hh + j (see `stage`), so the packed P
     //      registers are the B operand as they stand and the matching V^T fragment is ONE 16-byte read of 8 consecutive keys.

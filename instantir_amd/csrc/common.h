@@ -8,8 +8,24 @@ typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// element-type traits of the kernels that exist in an fp16 and a bf16 build (the VAE runs bf16: SDXL's VAE overflows fp16)
+template <typename E> struct ET;
+template <> struct ET<f16> {
+    using x4 = f16x4; using x8 = f16x8;
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct ET<bf16> {
+    using x4 = bf16x4; using x8 = bf16x8;
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+#define IIR_DT_F16 0
+#define IIR_DT_BF16 1
 
 #define IIR_OK 0
 #define IIR_EINVAL (-1)

@@ -57,6 +57,8 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     float* sk_slabs; int* sk_cnt;   // split-K workspace: fp32 partial tiles [tile][z][BM*BN] and per-tile arrival counters
     f16* Ct; long ldct; int tr_from, ct_vec;   // columns n >= tr_from are stored transposed: Ct[(n - tr_from) * ldct + m]
     int c_vec, r_vec;               // C / res rows allow 16-byte accesses (ld % 8 == 0, base 16-byte aligned)
+    int dtype;                      // IIR_DT_F16 / IIR_DT_BF16: element type of A, W, C, bias, rowbias, res
+    int c_f32;                      // C is float (plain epilogue, out_scale only): the VAE's attention scores
 };
 
 constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
@@ -73,8 +75,10 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int ST, bool CONV, int WAVES_M = 2>
+template <typename E, int BM, int BN, int ST, bool CONV, int WAVES_M = 2>
 __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_kernel(const Geo g) {
+    using E4 = typename ET<E>::x4;
+    using E8 = typename ET<E>::x8;     // (pointers stay f16-typed: both element types are 2 bytes; only conversions differ)
     constexpr int NW = WAVES_M * 2, NT = 64 * NW;   // waves laid out WAVES_M x 2 over the tile
     constexpr int WM = BM / WAVES_M, WN = BN / 2;   // wave tile
     constexpr int MI = WM / 16, NI = WN / 16;    // 16x16 MFMA tiles per wave
@@ -222,27 +226,27 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     // LDS-read latency is exposed after a barrier (with one workgroup per CU nothing else would hide it).  The barrier
     // also carries lgkmcnt(0): every wave's reads of tile kt are complete, so its buffer is refilled right away
     // (tile kt+ST), one tile further ahead than a refill-then-read order allows.
-    auto frags = [&](int buf, int s, f16x8 (&af)[MI], f16x8 (&bf)[NI]) {
+    auto frags = [&](int buf, int s, E8 (&af)[MI], E8 (&bf)[NI]) {
         const char* as = (const char*)(As + buf * BM * BK);
         const char* bs = (const char*)(Bs + buf * BN * BK);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *(const f16x8*)(as + a_off[s] + i * 16 * 128);
+        for (int i = 0; i < MI; ++i) af[i] = *(const E8*)(as + a_off[s] + i * 16 * 128);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bf[j] = *(const f16x8*)(bs + b_off[s] + j * 16 * 128);
+        for (int j = 0; j < NI; ++j) bf[j] = *(const E8*)(bs + b_off[s] + j * 16 * 128);
     };
-    auto mma = [&](const f16x8 (&af)[MI], const f16x8 (&bf)[NI]) {
+    auto mma = [&](const E8 (&af)[MI], const E8 (&bf)[NI]) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = ET<E>::mfma16(bf[j], af[i], acc[i][j]);
     };
     auto admit = [&](int tiles_after) {     // wait until only `tiles_after` later tiles are still in flight, all LDS reads done, barrier
         if (ST >= 4 && tiles_after >= 2) wait_vm_lgkm_and_barrier<(ST >= 4 ? 2 * LOADS : 0)>();
         else if (ST >= 3 && tiles_after >= 1) wait_vm_lgkm_and_barrier<(ST >= 3 ? LOADS : 0)>();
         else wait_vm_lgkm_and_barrier<0>();
     };
-    f16x8 a0[MI], b0[NI], a1[MI], b1[NI];
+    E8 a0[MI], b0[NI], a1[MI], b1[NI];
     {
         const int rem = nk - 1 - kt0;
         admit(rem < ST - 2 ? rem : ST - 2);
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
             for (int j = 0; j < NI; ++j) *(f32x4*)(mine + ((i * NI + j) * NT + tid) * 4) = acc[i][j];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int* flag = (int*)(smem + ST * (BM + BN) * BK * (int)sizeof(f16));     // first word of the prefetch scratch (unused until phase 2)
+        int* flag = (int*)(smem + ST * (BM + BN) * BK * (int)sizeof(E));     // first word of the prefetch scratch (unused until phase 2)
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -306,6 +310,19 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
             for (int j = 0; j < NI; ++j) acc[i][j] += *(const f32x4*)(other + ((i * NI + j) * NT + tid) * 4);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    if (g.c_f32) {      // fp32 output straight from the accumulators (a lane holds 4 consecutive columns of one row)
+        float* c32 = (float*)g.C;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * WM + i * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * WN + j * 16 + fq * 4;
+                if (m < g.M && n < g.N) *(f32x4*)(c32 + (long)m * g.ldc + n) = acc[i][j] * g.out_scale;
+            }
+        }
+        return;
+    }
     const bool paired = g.epi != IIR_EPI_PLAIN;
     const int cs = (paired ? BN : 2 * BN) + 32;                          // tile row stride in bytes: odd multiple of 32 mod 256
     char* ct = smem;
@@ -322,14 +339,14 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
                 const int n = n0 + lc;
                 if (n >= g.N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (g.bias) { f16x4 b = *(const f16x4*)(g.bias + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
-                if (rb) { f16x4 b = *(const f16x4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
+                if (g.bias) { E4 b = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
+                if (rb) { E4 b = *(const E4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
                 else if (g.act == IIR_ACT_GELU) for (int t = 0; t < 4; ++t) v[t] = gelu_erf_f(v[t]);
                 else if (g.act == IIR_ACT_QUICKGELU) for (int t = 0; t < 4; ++t) v[t] = v[t] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[t]));
-                f16x4 o;
-                for (int t = 0; t < 4; ++t) o[t] = (f16)v[t];
-                *(f16x4*)(ct + lr * cs + lc * 2) = o;
+                E4 o;
+                for (int t = 0; t < 4; ++t) o[t] = (E)v[t];
+                *(E4*)(ct + lr * cs + lc * 2) = o;
             }
         } else {
             // paired columns: in every 16-column group of the (row-permuted) weight the first 8 are the "value" rows and
@@ -341,19 +358,19 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
             for (int j = 0; j < NI; ++j) {
                 const int n = n0 + wn * WN + j * 16 + fq * 4;           // permuted column held by this lane
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (g.bias && n < g.N) { f16x4 ba = *(const f16x4*)(g.bias + n); for (int t = 0; t < 4; ++t) a[t] += (float)ba[t]; }
+                if (g.bias && n < g.N) { E4 ba = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) a[t] += (float)ba[t]; }
                 float b[4];
                 for (int t = 0; t < 4; ++t) b[t] = __shfl_xor(a[t], 32, 64);     // all lanes take part in the exchange
                 if (fq >= 2 || n >= g.N) continue;
                 const int lco = (wn * WN + j * 16) / 2 + fq * 4;        // output column inside the tile
-                f16x4 o;
+                E4 o;
                 if (g.epi == IIR_EPI_GEGLU) {
-                    for (int t = 0; t < 4; ++t) o[t] = (f16)(a[t] * gelu_erf_f(b[t]));
+                    for (int t = 0; t < 4; ++t) o[t] = (E)(a[t] * gelu_erf_f(b[t]));
                 } else {   // IIR_EPI_SFT: h * (gamma + 1) + beta, h from `res`
-                    f16x4 h = *(const f16x4*)(g.res + mr * g.ldr + n0 / 2 + lco);
-                    for (int t = 0; t < 4; ++t) o[t] = (f16)((float)h[t] * (a[t] + 1.0f) + b[t]);
+                    E4 h = *(const E4*)(g.res + mr * g.ldr + n0 / 2 + lco);
+                    for (int t = 0; t < 4; ++t) o[t] = (E)((float)h[t] * (a[t] + 1.0f) + b[t]);
                 }
-                *(f16x4*)(ct + lr * cs + lco * 2) = o;
+                *(E4*)(ct + lr * cs + lco * 2) = o;
             }
         }
     }
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     auto touch_next_weights = [&]() {
         const int per = (g.pf_lines + (int)gridDim.x - 1) / (int)gridDim.x;
         const long l0 = (long)blockIdx.x * per, last = g.pf_lines - 1;
-        char* scratch = smem + ST * (BM + BN) * BK * (int)sizeof(f16) + wave * 256;
+        char* scratch = smem + ST * (BM + BN) * BK * (int)sizeof(E) + wave * 256;
 #pragma unroll
         for (int i = 0; i < PF_TOUCHES; ++i) {
             long l = l0 + min(tid + i * NT, per - 1);
@@ -394,36 +411,36 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
                 const int idx = tid + k * NT;
                 if (TOTAL_T % NT != 0 && idx >= TOTAL_T) break;
                 const int c = idx / RC, rc = idx - c * RC;
-                f16x8 o;
+                E8 o;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) o[t] = (f16)((float)*(const f16*)(ct + (rc * 8 + t) * cs + c * 2) * g.out_scale);
-                *(f16x8*)(g.Ct + (long)(no_tile + c - g.tr_from) * g.ldct + m0 + rc * 8) = o;
+                for (int t = 0; t < 8; ++t) o[t] = (E)((float)*(const E*)(ct + (rc * 8 + t) * cs + c * 2) * g.out_scale);
+                *(E8*)(g.Ct + (long)(no_tile + c - g.tr_from) * g.ldct + m0 + rc * 8) = o;
             }
             return;
         }
         // (hipcc drains every LDS-DMA in flight at the next use of an ordinary load's result, so the touches are issued
         //  after the residuals have been consumed and ahead of the stores, which need no wait)
         if (fast) {
-            f16x8 o[CH];
+            E8 o[CH];
             if (use_res) {
-                f16x8 rr[CH];
+                E8 rr[CH];
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     const int c = min(tid + k * NT, TOTAL - 1), r = c / CPR, cc = c - r * CPR;
-                    rr[k] = *(const f16x8*)(g.res + (long)(m0 + r) * g.ldr + no_tile + cc * 8);
+                    rr[k] = *(const E8*)(g.res + (long)(m0 + r) * g.ldr + no_tile + cc * 8);
                 }
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     const int c = min(tid + k * NT, TOTAL - 1), r = c / CPR, cc = c - r * CPR;
-                    const f16x8 v = *(const f16x8*)(ct + r * cs + cc * 16);
-                    for (int t = 0; t < 8; ++t) o[k][t] = (f16)(((float)v[t] + (float)rr[k][t]) * g.out_scale);
+                    const E8 v = *(const E8*)(ct + r * cs + cc * 16);
+                    for (int t = 0; t < 8; ++t) o[k][t] = (E)(((float)v[t] + (float)rr[k][t]) * g.out_scale);
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     const int c = min(tid + k * NT, TOTAL - 1), r = c / CPR, cc = c - r * CPR;
-                    const f16x8 v = *(const f16x8*)(ct + r * cs + cc * 16);
-                    for (int t = 0; t < 8; ++t) o[k][t] = (f16)((float)v[t] * g.out_scale);
+                    const E8 v = *(const E8*)(ct + r * cs + cc * 16);
+                    for (int t = 0; t < 8; ++t) o[k][t] = (E)((float)v[t] * g.out_scale);
                 }
             }
             touch_next_weights();
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
             for (int k = 0; k < CH; ++k) {
                 const int c = tid + k * NT, r = c / CPR, cc = c - r * CPR;
                 if (TOTAL % NT != 0 && c >= TOTAL) break;
-                *(f16x8*)(g.C + (long)(m0 + r) * g.ldc + no_tile + cc * 8) = o[k];
+                *(E8*)(g.C + (long)(m0 + r) * g.ldc + no_tile + cc * 8) = o[k];
             }
         } else {
             // ragged edge / unaligned rows / per-image row remap: element-wise, speed irrelevant
@@ -447,13 +464,13 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
                     if (g.y_img_rows) mc = (long)img * g.y_img_rows + rem;
                     if (g.res_img_rows) mr = (long)img * g.res_img_rows + rem;
                 }
-                const f16* tp = (const f16*)(ct + r * cs + cc * 16);
+                const E* tp = (const E*)(ct + r * cs + cc * 16);
 #pragma unroll 1
                 for (int t = 0; t < 8 && n + t < No; ++t) {
                     float v = (float)tp[t];
-                    if (g.Ct && n + t >= g.tr_from) { g.Ct[(long)(n + t - g.tr_from) * g.ldct + mc] = (f16)(v * g.out_scale); continue; }
-                    if (use_res) v += (float)g.res[mr * g.ldr + n + t];
-                    g.C[mc * g.ldc + n + t] = (f16)(v * g.out_scale);
+                    if (g.Ct && n + t >= g.tr_from) { ((E*)g.Ct)[(long)(n + t - g.tr_from) * g.ldct + mc] = (E)(v * g.out_scale); continue; }
+                    if (use_res) v += (float)((const E*)g.res)[mr * g.ldr + n + t];
+                    ((E*)g.C)[mc * g.ldc + n + t] = (E)(v * g.out_scale);
                 }
             }
         }
@@ -463,8 +480,8 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA touches must land before the LDS is released
 }
 
-template <int BM, int BN, int ST, int WAVES_M = 2>
-int launch(const Geo& g0, bool conv, hipStream_t stream) {
+template <typename E, int BM, int BN, int ST, int WAVES_M = 2>
+int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
@@ -490,14 +507,24 @@ int launch(const Geo& g0, bool conv, hipStream_t stream) {
     const dim3 grid(8 * g.rm * g.rn * (g.splitk == 2 ? 2 : 1)), block(128 * WAVES_M);
     if (conv) {
         static bool attr_c = false;
-        if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
-        iir_launch(gemm_kernel<BM, BN, ST, true, WAVES_M>, grid, block, lds, stream, g);
+        if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
+        iir_launch(gemm_kernel<E, BM, BN, ST, true, WAVES_M>, grid, block, lds, stream, g);
     } else {
         static bool attr_g = false;
-        if (!attr_g) { (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, ST, false, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
-        iir_launch(gemm_kernel<BM, BN, ST, false, WAVES_M>, grid, block, lds, stream, g);
+        if (!attr_g) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
+        iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M>, grid, block, lds, stream, g);
     }
     return iir_launch_status();
+}
+
+// fp16 build of every tile / ring depth; bf16 build (the VAE) of the two-stage tiles the chooser picks for it
+template <int BM, int BN, int ST, int WAVES_M = 2>
+int launch(const Geo& g, bool conv, hipStream_t stream) {
+    if (g.dtype == IIR_DT_BF16) {
+        if constexpr (ST == 2 && WAVES_M == 2) return launch_t<bf16, BM, BN, ST, WAVES_M>(g, conv, stream);
+        else return IIR_EINVAL;
+    }
+    return launch_t<f16, BM, BN, ST, WAVES_M>(g, conv, stream);
 }
 
 struct TileShape { int bm, bn; };
@@ -549,7 +576,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // of K on exactly those (51.8 vs 44.8 us warm at K = 5120, equal at K = 11520, 73.9 vs 73.0 ms per step): the agent-scope
     // release per workgroup and the fp32 slab round trip cost more than the smaller operand fill saves.  The engine does
     // not pass a workspace unless IIR_SPLITK=1.
-    if (tile == 0 && g.sk_slabs && uses_splitk(g.M, g.N, g.K, g.sk_bytes)) {
+    if (tile == 0 && g.sk_slabs && g.dtype == IIR_DT_F16 && uses_splitk(g.M, g.N, g.K, g.sk_bytes)) {
         Geo g2 = g;
         g2.splitk = 2;
         return launch<128, 160, 3>(g2, conv, stream);
@@ -560,7 +587,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         // ring depth: with at most one workgroup per CU nothing else hides the tile latency, and a long K loop
         // amortises the deeper prologue -> 3 stages for the 64x160 tile (measured +17..40 % on K >= 2560, M*N = 2048x1280)
         const long blocks = (long)((g.M + kTiles[tile].bm - 1) / kTiles[tile].bm) * ((g.N + kTiles[tile].bn - 1) / kTiles[tile].bn);
-        const int stages = (tile == 5 && blocks <= 256 && g.K >= one_per_cu_min_k()) ? one_per_cu_stages() : IIR_DEFAULT_STAGES;
+        const int stages = (tile == 5 && blocks <= 256 && g.K >= one_per_cu_min_k() && g.dtype == IIR_DT_F16) ? one_per_cu_stages() : IIR_DEFAULT_STAGES;
         tile += 10 * stages;
     }
     switch (tile) {
@@ -614,6 +641,12 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     g.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     g.pf = (const char*)d->prefetch; g.pf_lines = d->prefetch ? (int)(d->prefetch_bytes / 128) : 0;
     finish_geo(g);
+    if (d->dtype != IIR_DT_F16 && d->dtype != IIR_DT_BF16) return IIR_EINVAL;
+    g.dtype = d->dtype;
+    if (d->c_f32) {
+        if (d->epi != IIR_EPI_PLAIN || d->bias || d->rowbias || d->res || d->Ct || d->act || d->ldc % 4 || (uintptr_t)d->C % 16 || d->splitk_ws) return IIR_EINVAL;
+        g.c_f32 = 1;
+    }
     if (d->Ct) {
         if (d->epi != IIR_EPI_PLAIN || d->tr_from < 0 || d->tr_from >= d->N || d->tr_from % 8 || d->ldct < d->M) return IIR_EINVAL;
         g.Ct = (f16*)d->Ct; g.ldct = d->ldct; g.tr_from = d->tr_from;
@@ -650,6 +683,8 @@ extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
     g.zero = (const f16*)c->zero_page;
     g.pf = (const char*)c->prefetch; g.pf_lines = c->prefetch ? (int)(c->prefetch_bytes / 128) : 0;
     finish_geo(g);
+    if (c->dtype != IIR_DT_F16 && c->dtype != IIR_DT_BF16) return IIR_EINVAL;
+    g.dtype = c->dtype;
     g.x_img_stride = c->x_img_stride ? c->x_img_stride : (int64_t)c->H * c->Wd * c->ldx;
     g.y_img_rows = c->y_img_rows; g.res_img_rows = c->res_img_rows;
     if (c->splitk_ws && c->splitk_ws_bytes > SK_CNT_BYTES) {

@@ -14,100 +14,127 @@ namespace {
 
 constexpr int GN_MAXC = 2560;
 
-// ---- GroupNorm pass 1: per (image, slab, group) partial sum / sum of squares ----------------------
+// Statistics are carried as (count, mean, M2 = sum of squared deviations) and merged with Chan's pairwise update in a FIXED
+// order: no E[x^2] - mean^2 cancellation (real SDXL activations have group means far above their spread), and bitwise
+// reproducible run to run.  Inside a thread the sums are taken about the thread's first sample, which is of the size of the
+// data, so the one-pass form is as well conditioned as a two-pass one.
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb <= 0.f) return;
+    const float tot = n + nb, d = mb - mean;
+    mean += d * (nb / tot);
+    m2 += m2b + d * d * (n * nb / tot);
+    n = tot;
+}
+
+// ---- GroupNorm pass 1: per (image, slab, group) partial (mean, M2) ------------------------------------
 // grid (nslab, R); each thread owns fixed 8-channel chunks so channel sums live in registers.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* X, long ldx, int HW, int C, int G, int pix_per_slab,
+template <typename E>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* Xp, long ldx, int HW, int C, int G, int pix_per_slab,
                                                        float* part /*[R][nslab][G][2]*/) {
-    // per-(pixel row, channel) partials, summed afterwards in a FIXED order: bitwise reproducible statistics
-    __shared__ float csum[2048], csq[2048];                 // prows * C <= 256 * 8 whenever nchunk <= 256
-    __shared__ float chs[GN_MAXC], chq[GN_MAXC];
+    using E8 = typename ET<E>::x8;
+    const E* X = (const E*)Xp;
+    __shared__ float cmean[2048], cm2[2048];                // per (pixel-row lane, channel) partials: prows * C <= 2048
+    __shared__ float chmean[GN_MAXC], chm2[GN_MAXC];
     const int r = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
     const int nchunk = C >> 3;
     const int p0 = slab * pix_per_slab;
     const int p1 = min(HW, p0 + pix_per_slab);
-    const f16* base = X + (long)r * HW * ldx;
-    // chunk columns handled by this thread: ch = tid % lanes_c (+ k*lanes_c), rows strided by prow count
+    const E* base = X + (long)r * HW * ldx;
     const int lanes_c = nchunk < 256 ? nchunk : 256;
     const int prows = 256 / lanes_c;
     const int tc = threadIdx.x % lanes_c, tp = threadIdx.x / lanes_c;
     for (int c0 = 0; c0 < nchunk; c0 += lanes_c) {            // one pass unless C > 2048
         const int ch = c0 + tc;
         if (tp < prows && ch < nchunk) {
-            float s[8], q[8];
+            float s[8], q[8], k0[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-            int p = p0 + tp;
+            for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; k0[j] = 0.f; }
+            int p = p0 + tp, cnt = 0;
+            if (p < p1) {
+                const E8 v = *(const E8*)(base + (long)p * ldx + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) k0[j] = (float)v[j];
+            }
             for (; p + 3 * prows < p1; p += 4 * prows) {            // 4 loads in flight per thread
-                f16x8 v[4];
+                E8 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *(const f16x8*)(base + (long)(p + u * prows) * ldx + ch * 8);
+                for (int u = 0; u < 4; ++u) v[u] = *(const E8*)(base + (long)(p + u * prows) * ldx + ch * 8);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
+                    for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j] - k0[j]; s[j] += f; q[j] += f * f; }
+                cnt += 4;
             }
             for (; p < p1; p += prows) {
-                const f16x8 v = *(const f16x8*)(base + (long)p * ldx + ch * 8);
+                const E8 v = *(const E8*)(base + (long)p * ldx + ch * 8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j] - k0[j]; s[j] += f; q[j] += f * f; }
+                cnt += 1;
             }
+            const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { csum[(tp * lanes_c + tc) * 8 + j] = s[j]; csq[(tp * lanes_c + tc) * 8 + j] = q[j]; }
+            for (int j = 0; j < 8; ++j) {
+                cmean[(tp * lanes_c + tc) * 8 + j] = k0[j] + s[j] * inv;
+                cm2[(tp * lanes_c + tc) * 8 + j] = fmaxf(q[j] - s[j] * s[j] * inv, 0.f);
+            }
         }
         __syncthreads();
         for (int c = threadIdx.x; c < lanes_c * 8 && c0 * 8 + c < C; c += 256) {
-            float s = 0.f, q = 0.f;
-            for (int t = 0; t < prows; ++t) { s += csum[t * lanes_c * 8 + c]; q += csq[t * lanes_c * 8 + c]; }
-            chs[c0 * 8 + c] = s; chq[c0 * 8 + c] = q;
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+            for (int t = 0; t < prows; ++t) {               // pixel-row lane t saw pixels p0 + t, p0 + t + prows, ...
+                const int first = p0 + t;
+                const float nt = first < p1 ? (float)((p1 - first + prows - 1) / prows) : 0.f;
+                chan_merge(n, mean, m2, nt, cmean[t * lanes_c * 8 + c], cm2[t * lanes_c * 8 + c]);
+            }
+            chmean[c0 * 8 + c] = mean; chm2[c0 * 8 + c] = m2;
         }
         __syncthreads();
     }
     const int cpg = C / G;
+    const float npix = (float)(p1 - p0);
     for (int gi = threadIdx.x; gi < G; gi += 256) {
-        float s = 0.f, q = 0.f;
-        for (int c = gi * cpg; c < (gi + 1) * cpg; ++c) { s += chs[c]; q += chq[c]; }
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int c = gi * cpg; c < (gi + 1) * cpg; ++c) chan_merge(n, mean, m2, npix, chmean[c], chm2[c]);
         float* o = part + (((long)r * nslab + slab) * G + gi) * 2;
-        o[0] = s; o[1] = q;
+        o[0] = mean; o[1] = m2;
     }
 }
 
-// ---- GroupNorm pass 2: reduce the slab partials to mean / rstd per (image, group) ------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int nslab, int G, float n_per_group, float eps,
-                                                          float* stat /*[R][G][2]*/) {
-    // 256 threads per image: thread = (slab lane, group); fixed-order tree over the slab lanes => reproducible
-    __shared__ float ss[256], sq[256];
+// ---- GroupNorm pass 2: merge the slab partials to mean / rstd per (image, group) ------------------
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int nslab, int G, int HW, int pix_per_slab, int cpg,
+                                                          float eps, float* stat /*[R][G][2]*/) {
+    // 256 threads per image: thread = (slab lane, group); fixed-order merge over the slab lanes => reproducible
+    __shared__ float sn[256], smean[256], sm2[256];
     const int r = blockIdx.x;
     const int lanes = 256 / G;                      // G <= 64 -> >= 4 slab lanes
     const int gi = threadIdx.x % G, sl = threadIdx.x / G;
-    float s = 0.f, q = 0.f;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
     if (sl < lanes) {
         const float* base = part + ((long)r * nslab * G + gi) * 2;
-        int k = sl;
-        for (; k + 3 * lanes < nslab; k += 4 * lanes) {
-            const float2 a = *(const float2*)(base + (long)k * G * 2), b = *(const float2*)(base + (long)(k + lanes) * G * 2);
-            const float2 c = *(const float2*)(base + (long)(k + 2 * lanes) * G * 2), d = *(const float2*)(base + (long)(k + 3 * lanes) * G * 2);
-            s += (a.x + b.x) + (c.x + d.x);
-            q += (a.y + b.y) + (c.y + d.y);
+        for (int k = sl; k < nslab; k += lanes) {
+            const float2 a = *(const float2*)(base + (long)k * G * 2);
+            const int p0 = k * pix_per_slab, p1 = min(HW, p0 + pix_per_slab);
+            chan_merge(n, mean, m2, (float)(p1 - p0) * (float)cpg, a.x, a.y);
         }
-        for (; k < nslab; k += lanes) { const float2 a = *(const float2*)(base + (long)k * G * 2); s += a.x; q += a.y; }
     }
-    ss[threadIdx.x] = s; sq[threadIdx.x] = q;
+    sn[threadIdx.x] = n; smean[threadIdx.x] = mean; sm2[threadIdx.x] = m2;
     __syncthreads();
     if (threadIdx.x < G) {
-        float ts = 0.f, tq = 0.f;
-        for (int l = 0; l < lanes; ++l) { ts += ss[l * G + threadIdx.x]; tq += sq[l * G + threadIdx.x]; }
-        const float mean = ts / n_per_group;
-        const float var = fmaxf(tq / n_per_group - mean * mean, 0.f);
-        stat[((long)r * G + threadIdx.x) * 2] = mean;
-        stat[((long)r * G + threadIdx.x) * 2 + 1] = rsqrtf(var + eps);
+        float tn = 0.f, tmean = 0.f, tm2 = 0.f;
+        for (int l = 0; l < lanes; ++l) chan_merge(tn, tmean, tm2, sn[l * G + threadIdx.x], smean[l * G + threadIdx.x], sm2[l * G + threadIdx.x]);
+        stat[((long)r * G + threadIdx.x) * 2] = tmean;
+        stat[((long)r * G + threadIdx.x) * 2 + 1] = rsqrtf(tm2 / tn + eps);
     }
 }
 
 // ---- GroupNorm pass 3: normalize + affine (+SiLU).  A thread owns fixed 8-channel chunks, so its 16
 // scale/shift coefficients live in registers and the pixel loop is load - 8 fma - store.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, long ldx, f16* Y, long ldy, int HW, int C, int G,
-                                                       int pix_per_blk, const float* stat, const f16* gamma,
-                                                       const f16* beta, int silu) {
+template <typename E>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* Xp, long ldx, f16* Yp, long ldy, int HW, int C, int G,
+                                                       int pix_per_blk, const float* stat, const f16* gammap,
+                                                       const f16* betap, int silu) {
+    using E8 = typename ET<E>::x8;
+    const E* X = (const E*)Xp; E* Y = (E*)Yp; const E* gamma = (const E*)gammap; const E* beta = (const E*)betap;
     const int r = blockIdx.y;
     const int cpg = C / G;
     const int nchunk = C >> 3;
@@ -117,12 +144,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, long ldx, f
     if (tp >= prows) return;
     const int p0 = blockIdx.x * pix_per_blk;
     const int p1 = min(HW, p0 + pix_per_blk);
-    const f16* xb = X + (long)r * HW * ldx;
-    f16* yb = Y + (long)r * HW * ldy;
+    const E* xb = X + (long)r * HW * ldx;
+    E* yb = Y + (long)r * HW * ldy;
     const float* st = stat + (long)r * G * 2;
     for (int ch = tc; ch < nchunk; ch += lanes_c) {
         float a[8], b[8];
-        const f16x8 gm = *(const f16x8*)(gamma + ch * 8), bt = *(const f16x8*)(beta + ch * 8);
+        const E8 gm = *(const E8*)(gamma + ch * 8), bt = *(const E8*)(beta + ch * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int gi = (ch * 8 + j) / cpg;
@@ -131,15 +158,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, long ldx, f
             b[j] = (float)bt[j] - mean * a[j];
         }
         for (int p = p0 + tp; p < p1; p += prows) {
-            const f16x8 v = *(const f16x8*)(xb + (long)p * ldx + ch * 8);
-            f16x8 o;
+            const E8 v = *(const E8*)(xb + (long)p * ldx + ch * 8);
+            E8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float f = fmaf((float)v[j], a[j], b[j]);
                 if (silu) f = silu_f(f);
-                o[j] = (f16)f;
+                o[j] = (E)f;
             }
-            *(f16x8*)(yb + (long)p * ldy + ch * 8) = o;
+            *(E8*)(yb + (long)p * ldy + ch * 8) = o;
         }
     }
 }
@@ -275,7 +302,68 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(f16* X, long ld, int 
     }
 }
 
+// ---- row softmax of fp32 scores, written as fp16 / bf16 probabilities (VAE mid-block attention: the scores never leave
+// fp32 before the softmax, as in the reference's fp32 VAE).  One workgroup per row, the row stays in registers.
+template <typename E>
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* S, long lds, f16* Pp, long ldp, int cols) {
+    using E4 = typename ET<E>::x4;
+    __shared__ float red[4];
+    const float* x = S + (long)blockIdx.x * lds;
+    E* y = (E*)Pp + (long)blockIdx.x * ldp;
+    const int nchunk = cols >> 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int MAXK = 16;                        // 256 threads x 4 floats x 16 = 16384 columns
+    f32x4 v[MAXK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = threadIdx.x + k * 256;
+        if (ch < nchunk) {
+            v[k] = *(const f32x4*)(x + ch * 4);
+            mx = fmaxf(fmaxf(mx, fmaxf(v[k][0], v[k][1])), fmaxf(v[k][2], v[k][3]));
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = threadIdx.x + k * 256;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[k][j] = __expf(v[k][j] - mx); sum += v[k][j]; }
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int ch = threadIdx.x + k * 256;
+        if (ch < nchunk) {
+            E4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (E)(v[k][j] * inv);
+            *(E4*)(y + ch * 4) = o;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int iir_softmax_rows_f32(const float* S, int64_t lds, void* P, int64_t ldp, int32_t rows, int32_t cols, int32_t dtype,
+                                    void* stream) {
+    (void)hipGetLastError();
+    if (!S || !P || rows <= 0 || cols <= 0 || cols % 4 || cols > 16384 || lds % 4 || ldp % 4) return IIR_EINVAL;
+    if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(softmax_rows_f32_kernel<bf16>, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, (long)lds, (f16*)P, (long)ldp, cols);
+    else if (dtype == IIR_DT_F16) hipLaunchKernelGGL(softmax_rows_f32_kernel<f16>, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, (long)lds, (f16*)P, (long)ldp, cols);
+    else return IIR_EINVAL;
+    return iir_launch_status();
+}
 
 extern "C" int iir_softmax_rows_f16(void* X, int64_t ld, int32_t rows, int32_t cols, void* stream) {
     (void)hipGetLastError();
@@ -284,13 +372,13 @@ extern "C" int iir_softmax_rows_f16(void* X, int64_t ld, int32_t rows, int32_t c
     return iir_launch_status();
 }
 
-extern "C" int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
-                                      int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
-                                      void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int iir_groupnorm_nhwc(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
+                                  int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
+                                  void* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
     (void)hipGetLastError();
     if (!X || !Y || !gamma || !beta || !workspace) return IIR_EINVAL;
     if (C % 8 || C > GN_MAXC || groups <= 0 || groups > 64 || C % groups || ldx % 8 || ldy % 8) return IIR_EINVAL;
-    if (R <= 0 || HW <= 0) return IIR_EINVAL;
+    if (R <= 0 || HW <= 0 || (dtype != IIR_DT_F16 && dtype != IIR_DT_BF16)) return IIR_EINVAL;
     // slabs: enough blocks to fill the chip, at least 8 pixels each (a 32x32 map of 1280-2560 channels took 14.6 us with
     // 64 workgroups walking 32 pixels each, 8 us with 256 walking 8)
     static const int min_pix = getenv("IIR_GN_MINPIX") ? atoi(getenv("IIR_GN_MINPIX")) : 8;
@@ -305,17 +393,23 @@ extern "C" int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64
     if ((part_floats + (int64_t)R * groups * 2) * 4 > workspace_bytes) return IIR_EINVAL;
     float* part = (float*)workspace;
     float* stat = part + part_floats;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, R), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, HW, C,
-                       groups, pps, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)part, nslab, groups,
-                       (float)HW * (float)(C / groups), eps, stat);
+    const hipStream_t st = (hipStream_t)stream;
     // apply: ~1024 blocks over the batch
     int nblk = (1024 + R - 1) / R;
     int ppb = (HW + nblk - 1) / nblk; if (ppb < 8) ppb = 8;
     nblk = (HW + ppb - 1) / ppb;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, R), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, (f16*)Y,
-                       (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
+    if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(nslab, R), dim3(256), 0, st, (const f16*)X, (long)ldx, HW, C, groups, pps, part);
+    else hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(nslab, R), dim3(256), 0, st, (const f16*)X, (long)ldx, HW, C, groups, pps, part);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(R), dim3(256), 0, st, (const float*)part, nslab, groups, HW, pps, C / groups, eps, stat);
+    if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(nblk, R), dim3(256), 0, st, (const f16*)X, (long)ldx, (f16*)Y, (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
+    else hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(nblk, R), dim3(256), 0, st, (const f16*)X, (long)ldx, (f16*)Y, (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
     return iir_launch_status();
+}
+
+extern "C" int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
+                                      int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+    return iir_groupnorm_nhwc(X, ldx, Y, ldy, R, HW, C, groups, gamma, beta, eps, silu, workspace, workspace_bytes, IIR_DT_F16, stream);
 }
 
 extern "C" int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups) { return (int64_t)R * 257 * groups * 2 * 4; }

@@ -59,18 +59,20 @@ __global__ void copy_add_kernel(const f16* src, long lds_, f16* dst, long ldd, l
 }
 
 // fp32 NCHW (B, C, H, W) -> f16 NHWC rows (rep*B, H*W, ldo), channels [0,C) written, repeated `rep` times
-__global__ void pack_latent_kernel(const float* x, int B, int C, int HW, f16* out, long ldo, int rep, float scale) {
+template <typename E>
+__global__ void pack_latent_kernel(const float* x, int B, int C, int HW, E* out, long ldo, int rep, float scale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * HW) return;
     const int b = (int)(i / HW), p = (int)(i % HW);
     for (int c = 0; c < C; ++c) {
-        const f16 v = (f16)(x[((long)b * C + c) * HW + p] * scale);
+        const E v = (E)(x[((long)b * C + c) * HW + p] * scale);
         for (int k = 0; k < rep; ++k) out[((long)(k * B + b) * HW + p) * ldo + c] = v;
     }
 }
 
 // f16 NHWC rows (R, H*W, ldi) channels [0,C) -> fp32 NCHW (R, C, H, W)
-__global__ void unpack_latent_kernel(const f16* in, long ldi, int R, int C, int HW, float* out) {
+template <typename E>
+__global__ void unpack_latent_kernel(const E* in, long ldi, int R, int C, int HW, float* out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)R * HW) return;
     const int r = (int)(i / HW), p = (int)(i % HW);
@@ -216,21 +218,33 @@ extern "C" int iir_copy_add_f16(const void* src, int64_t lds, void* dst, int64_t
     return iir_launch_status();
 }
 
-extern "C" int iir_pack_latent(const float* x, int32_t B, int32_t C, int32_t HW, void* out, int64_t ldo, int32_t rep,
-                               float scale, void* stream) {
+extern "C" int iir_pack_latent_t(const float* x, int32_t B, int32_t C, int32_t HW, void* out, int64_t ldo, int32_t rep,
+                                 float scale, int32_t dtype, void* stream) {
     (void)hipGetLastError();
     if (!x || !out || B <= 0 || C <= 0 || HW <= 0 || rep <= 0 || ldo < C) return IIR_EINVAL;
-    hipLaunchKernelGGL(pack_latent_kernel, dim3(nblk((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, B, C, HW,
-                       (f16*)out, (long)ldo, rep, scale);
+    if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(pack_latent_kernel<bf16>, dim3(nblk((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, (bf16*)out, (long)ldo, rep, scale);
+    else if (dtype == IIR_DT_F16) hipLaunchKernelGGL(pack_latent_kernel<f16>, dim3(nblk((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, (f16*)out, (long)ldo, rep, scale);
+    else return IIR_EINVAL;
+    return iir_launch_status();
+}
+
+extern "C" int iir_pack_latent(const float* x, int32_t B, int32_t C, int32_t HW, void* out, int64_t ldo, int32_t rep,
+                               float scale, void* stream) {
+    return iir_pack_latent_t(x, B, C, HW, out, ldo, rep, scale, IIR_DT_F16, stream);
+}
+
+extern "C" int iir_unpack_latent_t(const void* in, int64_t ldi, int32_t R, int32_t C, int32_t HW, float* out, int32_t dtype,
+                                   void* stream) {
+    (void)hipGetLastError();
+    if (!in || !out || R <= 0 || C <= 0 || HW <= 0 || ldi < C) return IIR_EINVAL;
+    if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(unpack_latent_kernel<bf16>, dim3(nblk((long)R * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, (long)ldi, R, C, HW, out);
+    else if (dtype == IIR_DT_F16) hipLaunchKernelGGL(unpack_latent_kernel<f16>, dim3(nblk((long)R * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)in, (long)ldi, R, C, HW, out);
+    else return IIR_EINVAL;
     return iir_launch_status();
 }
 
 extern "C" int iir_unpack_latent(const void* in, int64_t ldi, int32_t R, int32_t C, int32_t HW, float* out, void* stream) {
-    (void)hipGetLastError();
-    if (!in || !out || R <= 0 || C <= 0 || HW <= 0 || ldi < C) return IIR_EINVAL;
-    hipLaunchKernelGGL(unpack_latent_kernel, dim3(nblk((long)R * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)in,
-                       (long)ldi, R, C, HW, out);
-    return iir_launch_status();
+    return iir_unpack_latent_t(in, ldi, R, C, HW, out, IIR_DT_F16, stream);
 }
 
 extern "C" int iir_cfg_rescale_factor(const void* eps_nhwc, int64_t lde, int32_t B, int32_t C, int32_t HW, const float* coef,

@@ -54,14 +54,15 @@ class Arena:
     """Bump allocator over one fp16 device buffer.  Static op order => static addresses, which is
     what hipGraph capture needs."""
 
-    def __init__(self, device):
+    def __init__(self, device, dtype=F16):
         self.device = device
+        self.dtype = dtype
         self.buf = None
         self.off = 0
         self.high = 0
 
     def reserve(self, n_elems):
-        self.buf = torch.empty(n_elems, dtype=F16, device=self.device)
+        self.buf = torch.empty(n_elems, dtype=self.dtype, device=self.device)
 
     def alloc(self, rows, cols):
         n = (rows * cols + 127) // 128 * 128
@@ -69,7 +70,7 @@ class Arena:
         self.off += n
         self.high = max(self.high, self.off)
         if self.buf is None:      # dry run: hand out a meta view so shapes/strides still work
-            return torch.empty(rows, cols, dtype=F16, device="meta")
+            return torch.empty(rows, cols, dtype=self.dtype, device="meta")
         if self.off > self.buf.numel():
             raise RuntimeError("activation arena overflow (forward differs from its sizing run)")
         return self.buf[off:off + rows * cols].view(rows, cols)

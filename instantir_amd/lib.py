@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("Ct", C.c_void_p), ("ldct", C.c_int64), ("tr_from", C.c_int32),
+        ("dtype", C.c_int32), ("c_f32", C.c_int32),
     ]
 
 
@@ -53,6 +54,7 @@ class ConvDesc(C.Structure):
         ("x_img_stride", C.c_int64), ("y_img_rows", C.c_int32), ("res_img_rows", C.c_int32), ("pad_mode", C.c_int32),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+        ("dtype", C.c_int32),
     ]
 
 
@@ -95,15 +97,19 @@ SIGNATURES = {
     "iir_conv2d_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "iir_attention_d64_f16": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "iir_groupnorm_nhwc_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _P]),
+    "iir_groupnorm_nhwc": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _I32, _P]),
     "iir_groupnorm_workspace_bytes": (C.c_int64, [_I32, _I32]),
     "iir_layernorm_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _F, _P, _P, _I64, _I32, _I32, _I32, _I64, _P]),
     "iir_adaln_batch_f16": (C.c_int, [_P, _I32, _I32, _I32, _F, _I64, _I32, _I32, _I64, _P]),
     "iir_softmax_rows_f16": (C.c_int, [_P, _I64, _I32, _I32, _P]),
+    "iir_softmax_rows_f32": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _P]),
     "iir_sinusoid_f16": (C.c_int, [_P, _I32, _I32, _I32, _P, _I64, _I32, _P]),
     "iir_silu_f16": (C.c_int, [_P, _P, _I64, _P]),
     "iir_copy_add_f16": (C.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _I32, _P]),
     "iir_pack_latent": (C.c_int, [_P, _I32, _I32, _I32, _P, _I64, _I32, _F, _P]),
     "iir_unpack_latent": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
+    "iir_pack_latent_t": (C.c_int, [_P, _I32, _I32, _I32, _P, _I64, _I32, _F, _I32, _P]),
+    "iir_unpack_latent_t": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _I32, _P]),
     "iir_sched_step": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "iir_cfg_rescale_factor": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _F, _P, _P]),
     "iir_lcm_step": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P]),

@@ -22,9 +22,13 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def _chk2d(t, name):
-    if t.dtype != torch.float16 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
-        raise ValueError(f"{name}: expected a 2-D fp16 CUDA tensor with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+_DT = {torch.float16: 0, torch.bfloat16: 1}       # IIR_DT_F16 / IIR_DT_BF16
+
+
+def _chk2d(t, name, dtype=torch.float16):
+    """2-D CUDA tensor of `dtype` (fp16 unless the call runs the bf16 build: the VAE) with unit column stride."""
+    if t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a 2-D {dtype} CUDA tensor with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
 
 
 class LaunchProfiler:
@@ -107,7 +111,14 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
          tile=0, prefetch=None, splitk_ws=None, out_t=None):
     """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues).
     out_t = (Ct, tr_from): output columns >= tr_from go, transposed, to Ct[n - tr_from, m]; `out` then is (M, tr_from)."""
-    _chk2d(a, "a"); _chk2d(w, "w"); _chk2d(out, "out")
+    dt = a.dtype
+    if dt not in _DT:
+        raise ValueError(f"a: fp16 or bf16 expected, got {dt}")
+    c_f32 = out.dtype == torch.float32                 # fp32 output (plain epilogue only): the VAE's attention scores
+    _chk2d(a, "a", dt); _chk2d(w, "w", dt); _chk2d(out, "out", torch.float32 if c_f32 else dt)
+    for t_, n_ in ((bias, "bias"), (rowbias, "rowbias"), (res, "res")):
+        if t_ is not None and t_.dtype != dt:
+            raise ValueError(f"{n_}: dtype {t_.dtype} does not match the operands ({dt})")
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K or not w.is_contiguous():
@@ -122,12 +133,13 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     d.M, d.N, d.K = M, N, K
     d.bias = _p(bias)
     if rowbias is not None:
-        _chk2d(rowbias, "rowbias")
+        _chk2d(rowbias, "rowbias", dt)
         d.rowbias, d.ldrb, d.rows_per_rb = rowbias.data_ptr(), rowbias.stride(0), rows_per_rb
     if res is not None:
-        _chk2d(res, "res")
+        _chk2d(res, "res", dt)
         d.res, d.ldr = res.data_ptr(), res.stride(0)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
+    d.dtype, d.c_f32 = _DT[dt], int(c_f32)
     if tile == 0:       # the library decides; resolve the same choice here only to NAME the launch for the profiler
         tile = 4 if splitk_ws is not None and L.load().iir_gemm_uses_splitk(M, N, K, splitk_ws.numel()) else auto_tile(M, N, epi != EPI_PLAIN, K)
     if prefetch is not None:
@@ -136,7 +148,7 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
     if out_t is not None:
         ct, tr_from = out_t
-        _chk2d(ct, "out_t")
+        _chk2d(ct, "out_t", dt)
         if ct.shape[0] < N - tr_from or ct.shape[1] < M:
             raise ValueError("out_t must hold (N - tr_from, M)")
         d.Ct, d.ldct, d.tr_from = ct.data_ptr(), ct.stride(0), tr_from
@@ -153,9 +165,13 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     """x (R,H,W,Cin) NHWC view (pixel stride x.stride(2), image stride x.stride(0) free), w (Cout,k,k,Cin) contiguous,
     out (rows, Cout[/2]) 2-D view; image i's pixels start at row i*y_img_rows (0 = dense)."""
     R, H, Wd, Cin = x.shape
-    if x.dtype != torch.float16 or x.stride(3) != 1 or x.stride(1) != Wd * x.stride(2):
-        raise ValueError("x must be an NHWC fp16 view with dense rows (pixel and image strides are free)")
-    _chk2d(out, "out")
+    dt = x.dtype
+    if dt not in _DT or x.stride(3) != 1 or x.stride(1) != Wd * x.stride(2):
+        raise ValueError("x must be an NHWC fp16 / bf16 view with dense rows (pixel and image strides are free)")
+    _chk2d(out, "out", dt)
+    for t_, n_ in ((w, "w"), (bias, "bias"), (rowbias, "rowbias"), (res, "res")):
+        if t_ is not None and t_.dtype != dt:
+            raise ValueError(f"{n_}: dtype {t_.dtype} does not match x ({dt})")
     Cout = w.shape[0]
     if tuple(w.shape[1:]) != (ksize, ksize, Cin) or not w.is_contiguous():
         raise ValueError("w must be contiguous (Cout,k,k,Cin)")
@@ -167,11 +183,12 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     d.Cout, d.ksize, d.stride, d.upsample = Cout, ksize, stride, int(bool(upsample))
     d.bias = _p(bias)
     if rowbias is not None:
-        _chk2d(rowbias, "rowbias")
+        _chk2d(rowbias, "rowbias", dt)
         d.rowbias, d.ldrb, d.rows_per_rb = rowbias.data_ptr(), rowbias.stride(0), rows_per_rb
     if res is not None:
-        _chk2d(res, "res")
+        _chk2d(res, "res", dt)
         d.res, d.ldr = res.data_ptr(), res.stride(0)
+    d.dtype = _DT[dt]
     Hi, Wi = (2 * H, 2 * Wd) if upsample else (H, Wd)
     pad2 = 1 if pad_mode == 1 else 2 * (ksize // 2)
     Mo = R * ((Hi + pad2 - ksize) // stride + 1) * ((Wi + pad2 - ksize) // stride + 1)
@@ -179,7 +196,7 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     if tile == 0:       # as in gemm(): the library decides, this only names the launch
         Kc = ksize * ksize * Cin
         tile = 4 if splitk_ws is not None and L.load().iir_gemm_uses_splitk(Mo, Cout, Kc, splitk_ws.numel()) else auto_tile(Mo, Cout, epi != EPI_PLAIN, Kc)
-    d.zero_page = zero_page(x.device).data_ptr()
+    d.zero_page = zero_page(x.device).data_ptr()          # (all-zero bits are zero in fp16 and bf16 alike)
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
     if splitk_ws is not None:
@@ -243,13 +260,16 @@ def gn_workspace(device, R, groups=32):
 
 def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32, ws=None):
     """x, out: 2-D views (R*HW, C).  `ws`: scratch from gn_workspace() (a shared per-stream one if omitted)."""
-    _chk2d(x, "x"); _chk2d(out, "out")
+    dt = x.dtype
+    _chk2d(x, "x", dt if dt in _DT else torch.float16); _chk2d(out, "out", dt)
+    if gamma.dtype != dt or beta.dtype != dt:
+        raise ValueError(f"gamma / beta must have the activations' dtype ({dt})")
     Cc = x.shape[1]
     if ws is None:
         ws = _gn_workspace(x.device, R, groups)
-    L.check(L.load().iir_groupnorm_nhwc_f16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, HW, Cc, groups,
-                                            gamma.data_ptr(), beta.data_ptr(), eps, int(silu), ws.data_ptr(),
-                                            ws.numel() * 4, _stream()), "iir_groupnorm_nhwc_f16")
+    L.check(L.load().iir_groupnorm_nhwc(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, HW, Cc, groups,
+                                        gamma.data_ptr(), beta.data_ptr(), eps, int(silu), ws.data_ptr(),
+                                        ws.numel() * 4, _DT[dt], _stream()), "iir_groupnorm_nhwc")
     return out
 
 
@@ -307,18 +327,18 @@ def copy_add(src, dst, dst_off=0, add=None, add_scale=None, rows_per_scale=1):
 def pack_latent(x, out, rep=1, scale=1.0):
     """x fp32 (B,C,H,W) contiguous -> out 2-D fp16 view (rep*B*H*W, ld>=C)."""
     B, Cc, H, Wd = x.shape
-    assert x.dtype == torch.float32 and x.is_contiguous()
-    L.check(L.load().iir_pack_latent(x.data_ptr(), B, Cc, H * Wd, out.data_ptr(), out.stride(0), rep, scale, _stream()),
-            "iir_pack_latent")
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.dtype in _DT
+    L.check(L.load().iir_pack_latent_t(x.data_ptr(), B, Cc, H * Wd, out.data_ptr(), out.stride(0), rep, scale, _DT[out.dtype],
+                                       _stream()), "iir_pack_latent_t")
     return out
 
 
 def unpack_latent(x2d, out):
     """x2d fp16 view (R*H*W, ld) -> out fp32 (R,C,H,W)."""
     R, Cc, H, Wd = out.shape
-    assert out.dtype == torch.float32 and out.is_contiguous()
-    L.check(L.load().iir_unpack_latent(x2d.data_ptr(), x2d.stride(0), R, Cc, H * Wd, out.data_ptr(), _stream()),
-            "iir_unpack_latent")
+    assert out.dtype == torch.float32 and out.is_contiguous() and x2d.dtype in _DT
+    L.check(L.load().iir_unpack_latent_t(x2d.data_ptr(), x2d.stride(0), R, Cc, H * Wd, out.data_ptr(), _DT[x2d.dtype], _stream()),
+            "iir_unpack_latent_t")
     return out
 
 
@@ -376,6 +396,15 @@ def softmax_rows(x):
     _chk2d(x, "x")
     L.check(L.load().iir_softmax_rows_f16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], _stream()), "iir_softmax_rows_f16")
     return x
+
+
+def softmax_rows_f32(s, p):
+    """p = softmax over the columns of the fp32 scores s (cols <= 16384, % 4 == 0); p is fp16 or bf16."""
+    if s.dtype != torch.float32 or s.dim() != 2 or s.stride(1) != 1 or p.dtype not in _DT or p.shape != s.shape:
+        raise ValueError("softmax_rows_f32: s fp32 2-D, p fp16/bf16 of the same shape")
+    L.check(L.load().iir_softmax_rows_f32(s.data_ptr(), s.stride(0), p.data_ptr(), p.stride(0), s.shape[0], s.shape[1], _DT[p.dtype],
+                                          _stream()), "iir_softmax_rows_f32")
+    return p
 
 
 def blend_tiles(a, b, extent, vertical):

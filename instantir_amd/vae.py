@@ -3,14 +3,19 @@
 Reference call sites: `pipelines/sdxl_instantir.py:1370-1379` (encode + `latent_dist.sample()` x
 scaling_factor) and `:1668-1695` (`latents / scaling_factor` -> `vae.decode`), run there in fp32 after
 `upcast_vae` (:984-1001) because the SDXL VAE overflows fp16.  Spec text: `module/diffusers_vae/vae.py:46-350`,
-`:771-793`.  Here: fp16 storage, fp32 accumulation and fp32 GroupNorm statistics -- adequate for the
-seeded synthetic weights this build can test with; real SDXL-VAE weights need the bf16 variant of the same
-kernels and are NOT validated.
+`:771-793`.  Here the activations and weights are **bf16** by default (fp32 exponent range: nothing overflows where
+the reference's fp32 does not), with fp32 accumulation, fp32 GroupNorm statistics (merged mean / M2, no
+E[x^2] - mean^2) and fp32 attention scores through the softmax.  `dtype=torch.float16` builds the fp16 variant of
+the same kernels (3 more mantissa bits, but activations above 65504 become inf: `decode_latent` / `encode` then
+raise FloatingPointError instead of returning a black image).  Tolerance against the fp32 oracle is stated in
+tests/test_vae_gpu.py; no real SDXL-VAE checkpoint exists offline, so real-weight behaviour is unpinned.
 
-Kernels reused from the UNet path (NHWC): implicit-GEMM conv (3x3, 1x1, nearest-2x folded, the
+Kernels shared with the UNet path (NHWC): implicit-GEMM conv (3x3, 1x1, nearest-2x folded, the
 encoder's bottom/right-padded stride-2 conv), GroupNorm+SiLU, GEMM.  The single-head d = C attention of
-the mid block is three GEMMs around an in-place row softmax (`iir_softmax_rows_f16`): S = QK^T/sqrt(C),
-P = softmax(S), O = P V + b_v (rows of P sum to 1, so the V bias is added after the product).
+the mid block is three GEMMs around a row softmax: S = QK^T/sqrt(C) written as FP32 (`iir_gemm_desc.c_f32`),
+P = softmax(S) (`iir_softmax_rows_f32`, fp32 in, 16-bit out), O = P V + b_v (rows of P sum to 1, so the V bias
+is added after the product).  T x T scores limit the untiled decode to 16384 latent pixels (1024^2 images); larger
+images decode tile by tile (`enable_tiling()`), as BASELINE configs[3] asks.
 """
 from __future__ import annotations
 
@@ -20,15 +25,18 @@ import torch
 
 from . import ops
 from .config import VAEConfig
-from .engine import CPAD, F16, Arena, _NullOps
+from .engine import CPAD, Arena, _NullOps
 from .packing import conv_weight_nhwc
 
 
 class HipVAE:
-    def __init__(self, cfg: VAEConfig, sd: Dict[str, torch.Tensor], device):
+    def __init__(self, cfg: VAEConfig, sd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("HipVAE: dtype must be torch.bfloat16 (default) or torch.float16")
         self.cfg, self.device = cfg, torch.device(device)
+        self.dtype = dtype
         self.w: Dict[str, torch.Tensor] = {}
-        self.arena = Arena(self.device)
+        self.arena = Arena(self.device, dtype)
         self.o = ops
         self._gnws = ops.gn_workspace(self.device, 64, cfg.norm_groups)
         self._sized = {}
@@ -37,7 +45,9 @@ class HipVAE:
         self.tile_sample_size = 1024         # AutoencoderKL config.sample_size (autoencoder_kl.py:117-124)
         self.tile_overlap_factor = 0.25      # autoencoder_kl.py:124
         self.use_tiling = False              # `vae.enable_tiling()` (autoencoder_kl.py:130-143)
-        self.dtype_name = "fp16"
+        self.dtype_name = "bf16" if dtype == torch.bfloat16 else "fp16"
+        F16 = dtype          # (the rest of this class allocates its 16-bit tensors as `F16`: the VAE's element type)
+        self._E = dtype
         t = lambda n: sd[n].to(device=self.device, dtype=F16)
         for name in sd:
             if not name.endswith(".weight"):
@@ -112,14 +122,18 @@ class HipVAE:
         o.gemm(n, w[path + ".to_q.w"], q, bias=w[path + ".to_q.b"])
         o.gemm(n, w[path + ".to_k.w"], k, bias=w[path + ".to_k.b"])
         a = A.alloc(R * T, C)
-        s = A.alloc(T, T)
+        if T > 16384 or T % 4:
+            raise ValueError(f"VAE mid-block attention over {T} latent pixels: the untiled path handles up to 16384 (a 1024x1024 "
+                             "image); call vae.enable_tiling() for larger images (autoencoder_kl.py:130-136)")
+        s32 = A.alloc(T, 2 * T).view(torch.float32)                               # fp32 scores (T, T)
+        pr = A.alloc(T, T)                                                        # probabilities, 16-bit
         vt = A.alloc(C, T)
         for r in range(R):
             rows = slice(r * T, (r + 1) * T)
             o.gemm(w[path + ".to_v.w"], n[rows], vt)                               # V^T (bias added after P V)
-            o.gemm(q[rows], k[rows], s, out_scale=C ** -0.5)                      # S = Q K^T / sqrt(C)
-            o.softmax_rows(s)
-            o.gemm(s, vt, a[rows], bias=w[path + ".to_v.b"])                      # O = P V + b_v
+            o.gemm(q[rows], k[rows], s32, out_scale=C ** -0.5)                    # S = Q K^T / sqrt(C), kept in fp32
+            o.softmax_rows_f32(s32, pr)
+            o.gemm(pr, vt, a[rows], bias=w[path + ".to_v.b"])                     # O = P V + b_v
         o.gemm(a, w[path + ".to_out.0.w"], out, bias=w[path + ".to_out.0.b"], res=x)
         A.release(m)
         return out
@@ -150,7 +164,7 @@ class HipVAE:
         z = z.to(self.device, torch.float32).contiguous()
         B, _, h, wd = z.shape
         out = torch.empty(B, 4, 8 * h, 8 * wd, dtype=torch.float32, device=self.device)
-        zin = torch.zeros(B * h * wd, CPAD, dtype=F16, device=self.device)
+        zin = torch.zeros(B * h * wd, CPAD, dtype=self._E, device=self.device)
         ops.pack_latent(z, zin)
         self._run(("dec", B, h, wd), lambda: self._decode(zin, B, h, wd, out))
         return out[:, :3]
@@ -236,10 +250,12 @@ class HipVAE:
         Returns the UNscaled latent mean + std * eps (fp32)."""
         image = image.to(self.device, torch.float32).contiguous()
         B, _, H, W = image.shape
-        xin = torch.zeros(B * H * W, CPAD, dtype=F16, device=self.device)
+        xin = torch.zeros(B * H * W, CPAD, dtype=self._E, device=self.device)
         ops.pack_latent(image, xin)
         mom = torch.empty(B, 8, H // 8, W // 8, dtype=torch.float32, device=self.device)
         self._run(("enc", B, H, W), lambda: self._encode(xin, B, H, W, mom))
+        if not torch.isfinite(mom).all():
+            raise FloatingPointError(f"VAE encode produced non-finite moments (activation overflow in the {self.dtype_name} build)")
         mean, logvar = mom[:, :4], mom[:, 4:]
         std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))           # module/diffusers_vae/vae.py:774-777,792
         return mean + std * eps.to(self.device, torch.float32)

@@ -1,5 +1,9 @@
 """GPU parity: VAE decode / encode through the HIP engine vs the CPU fp32 oracle (tiny geometry), plus the
-two kernels added for it (row softmax, bottom/right-padded stride-2 conv)."""
+kernels added for it (row softmax fp16 and fp32->16-bit, bottom/right-padded stride-2 conv, bf16 GEMM / conv / GroupNorm).
+
+Tolerances (the reference runs its VAE in fp32, pipelines/sdxl_instantir.py:984-1001,1668-1674; the oracle is fp32):
+  bf16 build (default): 8 significant bits per stored activation -> pixel PSNR >= 33 dB asserted (measured values are logged
+  to gpurun_out/psnr.log); fp16 build: >= 40 dB.  The 8-bit image the pipeline returns quantises at 58.9 dB."""
 import math
 
 import pytest
@@ -10,8 +14,15 @@ pytestmark = pytest.mark.gpu
 
 
 def psnr(got, want):
+    import inspect
+    from conftest import record_psnr
     mse = ((got - want) ** 2).mean().item()
-    return 10 * math.log10(want.abs().max().item() ** 2 / max(mse, 1e-30))
+    v = 10 * math.log10(want.abs().max().item() ** 2 / max(mse, 1e-30))
+    record_psnr("vae." + inspect.stack()[1].function, v)
+    return v
+
+
+BAR = {torch.bfloat16: 33.0, torch.float16: 40.0}
 
 
 @pytest.fixture(scope="module")
@@ -53,14 +64,71 @@ def test_conv_asymmetric_pad_stride2(dev):
     assert (out.float().cpu() - want).abs().max().item() < 5e-3
 
 
-@pytest.fixture(scope="module")
-def vae_env(dev):
+@pytest.fixture(scope="module", params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def vae_env(dev, request):
+    """Weights are generated IN the build's element type, so the fp32 oracle sees exactly the stored values and the
+    comparison isolates the arithmetic."""
     from instantir_amd import weights as W
     from instantir_amd.config import VAEConfig
     from instantir_amd.vae import HipVAE
     vc = VAEConfig.tiny()
-    sd = W.synth_state_dict(W.vae_decoder_specs(vc) + W.vae_encoder_specs(vc), 21)
-    return vc, sd, HipVAE(vc, sd, dev)
+    sd = W.synth_state_dict(W.vae_decoder_specs(vc) + W.vae_encoder_specs(vc), 21, dtype=request.param)
+    return vc, sd, HipVAE(vc, sd, dev, dtype=request.param)
+
+
+def test_softmax_rows_f32(dev):
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for dt, tol in [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)]:
+        for rows, cols in [(7, 64), (33, 1000), (4, 16384)]:
+            x = (torch.randn(rows, cols, generator=g) * 30).to(dev)                # fp32 scores far outside fp16-exp range
+            want = torch.softmax(x, dim=-1).cpu()
+            p = torch.zeros(rows, cols, dtype=dt, device=dev)
+            ops.softmax_rows_f32(x, p)
+            torch.cuda.synchronize()
+            assert (p.float().cpu() - want).abs().max().item() <= tol * want.max().item() + 1e-7
+
+
+def test_gemm_bf16_and_fp32_output(dev):
+    """bf16 build of the GEMM (iir_gemm_desc.dtype) and the fp32-output epilogue (c_f32) the VAE attention uses."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(2)
+    M, N, K = 300, 132, 256
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    want = a.float() @ w.float().T + b.float()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out, bias=b.to(dev))
+    s32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), s32, out_scale=0.5)
+    h16 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(a.half().to(dev), w.half().to(dev), h16, out_scale=0.5)
+    torch.cuda.synchronize()
+    assert (out.float().cpu() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item() + 1e-3
+    plain = 0.5 * (a.float() @ w.float().T)
+    assert (s32.cpu() - plain).abs().max().item() <= 1e-4 * plain.abs().max().item() + 1e-5          # fp32 accumulate, fp32 out
+    assert (h16.cpu() - plain).abs().max().item() <= 1e-4 * plain.abs().max().item() + 1e-5          # (bf16 values are exact in fp16 here? no: a.half() of bf16 is exact)
+
+
+def test_groupnorm_large_mean_small_spread(dev):
+    """GroupNorm statistics as merged (mean, M2): a group whose mean is 300x its spread (E[x^2] - mean^2 would lose
+    the variance to cancellation in fp32: 1e5^2 * 2^-24 ~ 600 >> spread^2)."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(5)
+    R, HW, C, G = 2, 40 * 40, 128, 32
+    for dt in (torch.float16, torch.bfloat16):
+        base = 3000.0 if dt == torch.float16 else 1.0e5
+        x = (base + torch.randn(R, C, 40, 40, generator=g) * (base / 300)).to(dt)
+        gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(dt), (0.1 * torch.randn(C, generator=g)).to(dt)
+        want = F.group_norm(x.double(), G, gamma.double(), beta.double(), 1e-6).float()
+        x2d = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(dev)
+        out = torch.empty_like(x2d)
+        ops.groupnorm(x2d, out, R, HW, gamma.to(dev), beta.to(dev), 1e-6, False, G)
+        torch.cuda.synchronize()
+        got = out.float().cpu().reshape(R, 40, 40, C).permute(0, 3, 1, 2)
+        tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -10
+        assert (got - want).abs().max().item() <= tol * want.abs().max().item() * 2
 
 
 def test_vae_decode_matches_oracle(vae_env):
@@ -72,7 +140,7 @@ def test_vae_decode_matches_oracle(vae_env):
     got = hv.decode(z).cpu()
     assert got.shape == want.shape == (2, 3, 64, 64)
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p > 40, p
+    assert torch.isfinite(got).all() and p > BAR[hv.dtype], p
     img = hv.decode_latent(z * vc.scaling_factor, "pt")
     assert img.min().item() >= 0 and img.max().item() <= 1
     assert len(hv.decode_latent(z * vc.scaling_factor, "pil")) == 2
@@ -87,7 +155,7 @@ def test_vae_encode_matches_oracle(vae_env):
     want = OV.encode({k: v.float() for k, v in sd.items()}, vc, img, eps)
     got = hv.encode(img, eps).cpu()
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p > 40, p
+    assert torch.isfinite(got).all() and p > BAR[hv.dtype], p
 
 
 def test_pipeline_pixels_in_pixels_out(vae_env, dev):
@@ -125,9 +193,8 @@ def test_pipeline_pixels_in_pixels_out(vae_env, dev):
                      init_noise=noise, num_inference_steps=3, guidance_scale=5.0, sampler="ddim")
     want = (OV.decode(PV, vc, lat / vc.scaling_factor) / 2 + 0.5).clamp(0, 1)
     assert got.shape == (B, 3, 128, 128)
-    mse = ((got - want) ** 2).mean().item()
-    p = 10 * math.log10(1.0 / max(mse, 1e-30))
-    assert p > 35, p
+    p = psnr(got, want)
+    assert p > BAR[hv.dtype] - 5, p            # encode -> 3 denoising steps -> decode: the three stages' errors add
 
 
 def test_vae_tiled_decode_matches_oracle(vae_env):
@@ -141,4 +208,57 @@ def test_vae_tiled_decode_matches_oracle(vae_env):
     got = hv.decode_tiled(z, sample_size=128).cpu()
     assert got.shape == want.shape
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p > 40, p
+    assert torch.isfinite(got).all() and p > BAR[hv.dtype], p
+    # the switch the reference exposes (autoencoder_kl.py:130-136, 270-272): decode_latent tiles once enabled
+    hv.tile_sample_size = 128
+    plain = hv.decode_latent(z * vc.scaling_factor, "pt").cpu()
+    hv.enable_tiling()
+    tiled = hv.decode_latent(z * vc.scaling_factor, "pt").cpu()
+    hv.disable_tiling()
+    hv.tile_sample_size = 1024
+    assert torch.equal(tiled, (got / 2 + 0.5).clamp(0, 1)) and not torch.equal(tiled, plain)
+
+
+def test_vae_activation_overflow(dev):
+    """SDXL's VAE carries activations beyond the fp16 range, which is why the reference upcasts it to fp32
+    (pipelines/sdxl_instantir.py:984-1001).  With conv_in scaled so the mid block runs at ~1e5: the bf16 build still
+    matches the fp32 oracle, the fp16 build fails loudly (FloatingPointError) instead of returning a black image."""
+    from instantir_amd import weights as W
+    from instantir_amd.config import VAEConfig
+    from instantir_amd.vae import HipVAE
+    from oracle import vae as OV
+    vc = VAEConfig.tiny()
+    sd = W.synth_state_dict(W.vae_decoder_specs(vc), 23, dtype=torch.bfloat16)
+    sd["decoder.conv_in.weight"] = (sd["decoder.conv_in.weight"].float() * 4.0e4).bfloat16()
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(1, 4, 8, 8, generator=g)
+    P = {k: v.float() for k, v in sd.items()}
+    want = OV.decode(P, vc, z)
+    assert torch.isfinite(want).all()
+    got = HipVAE(vc, sd, dev, dtype=torch.bfloat16).decode(z).cpu()
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p > 30, p
+    with pytest.raises(FloatingPointError):
+        HipVAE(vc, sd, dev, dtype=torch.float16).decode_latent(z * vc.scaling_factor, "pt")
+
+
+def test_vae_tiled_decode_full_size_properties(dev):
+    """BASELINE configs[3] geometry: a 2048x2048 image = 256x256 latent through the full-size SDXL decoder, tiled
+    (3 x 3 tiles of 128 latent px, stride 96, 256-px blends).  The fp32 oracle would need ~1 h for this, so the check is by
+    properties: shape, finiteness, and that the un-blended interior of tile (0, 0) is bit-identical to decoding that tile alone."""
+    from instantir_amd import weights as W
+    from instantir_amd.config import VAEConfig
+    from instantir_amd.vae import HipVAE
+    vc = VAEConfig.sdxl()
+    hv = HipVAE(vc, W.synth_state_dict(W.vae_decoder_specs(vc), 31, device=dev, dtype=torch.bfloat16), dev)
+    g = torch.Generator().manual_seed(10)
+    z = torch.randn(1, 4, 256, 256, generator=g)
+    with pytest.raises(ValueError):
+        hv.decode(z)                                     # untiled: 65536 latent pixels exceed the score buffer -> clear error
+    hv.enable_tiling()
+    img = hv.decode_latent(z * vc.scaling_factor, "pt")
+    assert img.shape == (1, 3, 2048, 2048) and torch.isfinite(img).all()
+    zz = (z * vc.scaling_factor).to(dev) / vc.scaling_factor             # what decode_latent hands the decoder, bit for bit
+    alone = (hv.decode(zz[:, :, :128, :128].contiguous()) / 2 + 0.5).clamp(0, 1)
+    assert torch.equal(img[:, :, :768, :768], alone[:, :, :768, :768])
+
