@@ -25,8 +25,10 @@ def gemm_bench():
         a = torch.randn(M, K, device=dev).half(); w = (torch.randn(N, K, device=dev) * K ** -0.5).half()
         out = torch.empty(M, N, device=dev, dtype=torch.half)
         row = f"gemm M={M:6d} N={N:6d} K={K:5d}:"
+        geglu = os.environ.get("GEGLU", "0") == "1"
+        outg = torch.empty(M, N // 2, device=dev, dtype=torch.half)
         for tile in TILES:
-            t = timeit(lambda: ops.gemm(a, w, out, tile=tile))
+            t = timeit(lambda: ops.gemm(a, w, outg, tile=tile, epi=ops.EPI_GEGLU) if geglu else ops.gemm(a, w, out, tile=tile))
             row += f"  t{tile} {2*M*N*K/t/1e12:6.0f}"
         t = timeit(lambda: torch.matmul(a, w.T, out=out))
         row += f"  | hipblaslt {2*M*N*K/t/1e12:7.1f} TF"
