@@ -87,19 +87,31 @@ class Arena:
 
 def _merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], scaling: float) -> Dict[str, torch.Tensor]:
     """W' = W + s * B A (linear) / W'[o,i,:,:] = W + s * sum_r B[o,r] A[r,i,:,:] (conv): the enabled-adapter
-    forward of peft folded into a second weight copy, merged in fp32."""
+    forward of peft folded into a second weight copy.  The rank-r product runs on this
+    library's own GEMM (`iir_gemm_f16`: fp32 accumulation, W added as the epilogue's residual) -- no vendor BLAS on the
+    product's set-up path either.  The rank is zero-padded to one K tile (64)."""
     out = dict(sd)
     for k in lora:
         if not k.endswith(".lora_A.weight"):
             continue
         path = k[: -len(".lora_A.weight")]
-        a, b = lora[k].float(), lora[path + ".lora_B.weight"].float()
-        w = sd[path + ".weight"].float()
-        if w.dim() == 2:
-            w = w + scaling * (b @ a)
-        else:
-            w = w + scaling * torch.einsum("or,rikl->oikl", b[:, :, 0, 0], a)
-        out[path + ".weight"] = w.to(sd[path + ".weight"].dtype)
+        w = sd[path + ".weight"]
+        dev = w.device
+        if not w.is_cuda:
+            raise RuntimeError("_merge_lora: weights must be on the GPU (the merge runs in the HIP library)")
+        a, b = lora[k].to(dev), lora[path + ".lora_B.weight"].to(dev)
+        r = a.shape[0]
+        rp = (r + 63) // 64 * 64
+        n_out = w.shape[0]
+        kk = w.numel() // n_out
+        bs = torch.zeros(n_out, rp, dtype=F16, device=dev)                      # s * B, [N][r]
+        bs[:, :r] = (b.reshape(n_out, r).float() * scaling).to(F16)
+        at = torch.zeros(kk, rp, dtype=F16, device=dev)                         # A^T, [K][r]: the GEMM's "weight" operand
+        at[:, :r] = a.reshape(r, kk).t().to(F16)
+        w2 = w.reshape(n_out, kk).to(F16).contiguous()
+        merged = torch.empty_like(w2)
+        ops.gemm(bs, at, merged, res=w2)
+        out[path + ".weight"] = merged.reshape(w.shape).to(w.dtype)
     return out
 
 
