@@ -117,3 +117,26 @@ def test_aggregator_matches_oracle(env):
         p = psnr(_to_nchw(d, R, h, w_.shape[3]), w_)
         assert p >= 50, (k, p)
     assert psnr(_to_nchw(mid, R, wm.shape[2], wm.shape[3]), wm) >= 50
+
+
+def test_merged_lora_equals_side_branch(env):
+    """W + s*B*A folded into a second weight copy by the library's own GEMM (engine._merge_lora) == peft's side branch
+    (SURVEY 8a row L0), linear and conv (k x k `lora_A`, 1x1 `lora_B`), rank zero-padded to a K tile; fp16 tolerance."""
+    import numpy as np
+    from instantir_amd.engine import _merge_lora
+    from oracle import nets
+    dev = env[5]
+    g = torch.Generator().manual_seed(0)
+    sd = {"lin.weight": torch.randn(24, 16, generator=g).half(), "lin.bias": torch.randn(24, generator=g).half(),
+          "cv.weight": torch.randn(12, 8, 3, 3, generator=g).half(), "cv.bias": torch.randn(12, generator=g).half()}
+    lora = {"lin.lora_A.weight": torch.randn(4, 16, generator=g).half(), "lin.lora_B.weight": torch.randn(24, 4, generator=g).half(),
+            "cv.lora_A.weight": torch.randn(4, 8, 3, 3, generator=g).half(), "cv.lora_B.weight": torch.randn(12, 4, 1, 1, generator=g).half()}
+    merged = {k: v.float().cpu() for k, v in _merge_lora({k: v.to(dev) for k, v in sd.items()}, {k: v.to(dev) for k, v in lora.items()}, 0.25).items()}
+    sdf = {k: v.float() for k, v in sd.items()}
+    lo = dict({k: v.float() for k, v in lora.items()}, scaling=0.25)
+    x = torch.randn(5, 16, generator=g)
+    np.testing.assert_allclose(nets.linear(merged, "lin", x).numpy(), nets.linear(sdf, "lin", x, lo).numpy(), rtol=4e-3, atol=2e-2)
+    im = torch.randn(2, 8, 7, 7, generator=g)
+    for stride in (1, 2):
+        np.testing.assert_allclose(nets.conv2d(merged, "cv", im, stride=stride).numpy(),
+                                   nets.conv2d(sdf, "cv", im, stride=stride, lora=lo).numpy(), rtol=4e-3, atol=4e-2)
