@@ -64,6 +64,9 @@ typedef struct iir_gemm_desc {
                                    /*   overflows fp16 (pipelines/sdxl_instantir.py:984-1001,1668-1674)                     */
     int32_t c_f32;                 /* != 0: C is float [M][N] (ldc in floats, plain epilogue, out_scale only): the VAE     */
                                    /*   mid-block attention scores stay fp32 through their softmax                          */
+    const void* wscale;            /* != NULL: W holds fp8-E4M3 (OCP) BYTES [N][K] and wscale[n] (fp32, 16-byte aligned) is */
+                                   /*   the scale of row n: C = epi((A8 . W8^T) * wscale[n] ...), A converted to fp8 in the */
+                                   /*   kernel (BASELINE configs[4]: "fp8 MFMA weights" for the LCM single-step path)       */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections

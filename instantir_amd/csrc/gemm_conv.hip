@@ -59,6 +59,7 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     int c_vec, r_vec;               // C / res rows allow 16-byte accesses (ld % 8 == 0, base 16-byte aligned)
     int dtype;                      // IIR_DT_F16 / IIR_DT_BF16: element type of A, W, C, bias, rowbias, res
     int c_f32;                      // C is float (plain epilogue, out_scale only): the VAE's attention scores
+    const float* wscale;            // W8 build: W holds fp8-E4M3 bytes [N][K], wscale[n] its per-output-channel scale (fp32)
 };
 
 constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
@@ -75,18 +76,28 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <typename E, int BM, int BN, int ST, bool CONV, int WAVES_M = 2>
+// W8 (BASELINE configs[4]: "fp8 MFMA weights"): the weight operand is fp8-E4M3 with one fp32 scale per output channel.  Its
+// tile image has 64-byte rows (64 K values), 16 rows per LDS-DMA instruction, 16-byte chunk c of row r stored at chunk
+// c ^ ((r >> 2) & 3) (conflict-free 8-byte fragment reads); the activation tile stays fp16 in LDS and each A fragment is
+// converted to fp8 in registers (v_cvt_scalef32_pk_fp8_f16, scale 1) -- 4 conversions per fragment, reused by all NI column
+// tiles -- so the MFMA is v_mfma_f32_16x16x32_fp8_fp8.  Staged bytes per K tile drop from (BM + BN) * 128 to
+// BM * 128 + BN * 64: the weight panel, which dominates the level-2 projections' fill, halves.
+template <typename E, int BM, int BN, int ST, bool CONV, int WAVES_M = 2, bool W8 = false>
 __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_kernel(const Geo g) {
+    static_assert(!(W8 && CONV), "the fp8-weight build covers the linear layers only");
     using E4 = typename ET<E>::x4;
     using E8 = typename ET<E>::x8;     // (pointers stay f16-typed: both element types are 2 bytes; only conversions differ)
     constexpr int NW = WAVES_M * 2, NT = 64 * NW;   // waves laid out WAVES_M x 2 over the tile
     constexpr int WM = BM / WAVES_M, WN = BN / 2;   // wave tile
     constexpr int MI = WM / 16, NI = WN / 16;    // 16x16 MFMA tiles per wave
-    constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;   // glds instructions per wave per K tile
+    constexpr int B_GROUPS = W8 ? BN / 16 : BN / 8;                   // LDS-DMA instructions that cover the weight tile
+    constexpr int A_INST = BM / 8 / NW, B_INST = (B_GROUPS + NW - 1) / NW;   // glds instructions per wave per K tile
+    constexpr int B_STAGE_BYTES = W8 ? BN * 64 : BN * 128;
+    constexpr int RING_BYTES = ST * (BM * 128 + B_STAGE_BYTES);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16* As = (f16*)smem;                       // [ST][BM][64]
-    f16* Bs = As + ST * BM * BK;                // [ST][BN][64]
-    constexpr int LOADS = A_INST + B_INST;      // LDS-DMA instructions per wave per stage
+    f16* Bs = As + ST * BM * BK;                // [ST][BN][64]  (W8: [ST][BN][64 bytes])
+    constexpr int LOADS = A_INST + B_INST;      // LDS-DMA instructions per wave per stage (every wave issues exactly this many)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -134,9 +145,16 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     const f16* b_src[B_INST];
 #pragma unroll
     for (int i = 0; i < B_INST; ++i) {
-        int n = n0 + (i * NW + wave) * 8 + srow;
-        if (n >= g.N) n = g.N - 1;
-        b_src[i] = g.W + (long)n * g.K + schunk * 8;
+        if (!W8) {
+            int n = n0 + (i * NW + wave) * 8 + srow;
+            if (n >= g.N) n = g.N - 1;
+            b_src[i] = g.W + (long)n * g.K + schunk * 8;
+        } else {                                      // 16 rows of 64 bytes per instruction; lane = (row, 16-byte chunk)
+            const int r = (i * NW + wave) * 16 + (lane >> 2);
+            int n = n0 + r;
+            if (n >= g.N) n = g.N - 1;
+            b_src[i] = (const f16*)((const char*)g.W + (long)n * g.K + (((lane & 3) ^ ((r >> 2) & 3)) * 16));
+        }
     }
 
     // conv gather state: stage() is called for consecutive K tiles, so the (tap, channel) walk is incremental -- per tile one
@@ -191,8 +209,21 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
                 if (++cv_tap < g.ks * g.ks) conv_tap(cv_tap);
             }
         }
+        if (!W8) {
 #pragma unroll
-        for (int i = 0; i < B_INST; ++i) glds16(b_src[i] + k0, bs + (i * NW + wave) * 8 * BK);
+            for (int i = 0; i < B_INST; ++i) glds16(b_src[i] + k0, bs + (i * NW + wave) * 8 * BK);
+        } else {
+            char* bs8 = (char*)Bs + buf * B_STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < B_INST; ++i) {
+                if (B_GROUPS % NW == 0 || i * NW + wave < B_GROUPS) {
+                    glds16((const char*)b_src[i] + k0, bs8 + (i * NW + wave) * 1024);
+                } else {     // a wave without a row group this round still issues ONE vector-memory op, so the counted
+                             // vmcnt waits mean the same thing in every wave: a 4-byte touch of the tile's first line
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g.W, (LDS_AS void*)(smem + RING_BYTES + wave * 256), 4, 0, 0);
+                }
+            }
+        }
     };
 
     // ---- fragment read offsets (bytes inside a tile image) --------------------------------------
@@ -202,7 +233,8 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     for (int s = 0; s < 2; ++s) {
         const int phys = (s * 4 + fq) ^ (frow & 7);
         a_off[s] = (wm * WM + frow) * 128 + phys * 16;
-        b_off[s] = (wn * WN + frow) * 128 + phys * 16;
+        if (!W8) b_off[s] = (wn * WN + frow) * 128 + phys * 16;
+        else b_off[s] = (wn * WN + frow) * 64 + ((((fq >> 1) + 2 * s) ^ ((frow >> 2) & 3)) * 16) + (fq & 1) * 8;     // (WN % 16 == 0)
     }
 
     f32x4 acc[MI][NI];
@@ -226,27 +258,48 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     // LDS-read latency is exposed after a barrier (with one workgroup per CU nothing else would hide it).  The barrier
     // also carries lgkmcnt(0): every wave's reads of tile kt are complete, so its buffer is refilled right away
     // (tile kt+ST), one tile further ahead than a refill-then-read order allows.
-    auto frags = [&](int buf, int s, E8 (&af)[MI], E8 (&bf)[NI]) {
+    using BF = std::conditional_t<W8, long, E8>;       // weight fragment: 8 fp8 bytes or 8 halves
+    auto frags = [&](int buf, int s, E8 (&af)[MI], BF (&bf)[NI]) {
         const char* as = (const char*)(As + buf * BM * BK);
-        const char* bs = (const char*)(Bs + buf * BN * BK);
+        const char* bs = (const char*)Bs + buf * B_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = *(const E8*)(as + a_off[s] + i * 16 * 128);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bf[j] = *(const E8*)(bs + b_off[s] + j * 16 * 128);
+        for (int j = 0; j < NI; ++j) bf[j] = *(const BF*)(bs + b_off[s] + j * 16 * (W8 ? 64 : 128));
     };
-    auto mma = [&](const E8 (&af)[MI], const E8 (&bf)[NI]) {
+    auto mma = [&](const E8 (&af)[MI], const BF (&bf)[NI]) {
+        if constexpr (!W8) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                acc[i][j] = ET<E>::mfma16(bf[j], af[i], acc[i][j]);
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = ET<E>::mfma16(bf[j], af[i], acc[i][j]);
+        } else {
+            long a8[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {          // 8 halves -> 8 fp8 (E4M3, round to nearest even, saturating), k order kept
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                s16x2 lo = {0, 0}, hi = {0, 0};
+                lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, (f16x2){af[i][0], af[i][1]}, 1.0f, false);
+                lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, (f16x2){af[i][2], af[i][3]}, 1.0f, true);
+                hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, (f16x2){af[i][4], af[i][5]}, 1.0f, false);
+                hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, (f16x2){af[i][6], af[i][7]}, 1.0f, true);
+                a8[i] = (long)(unsigned)__builtin_bit_cast(int, lo) | ((long)__builtin_bit_cast(int, hi) << 32);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf[j], a8[i], acc[i][j], 0, 0, 0);
+        }
     };
     auto admit = [&](int tiles_after) {     // wait until only `tiles_after` later tiles are still in flight, all LDS reads done, barrier
         if (ST >= 4 && tiles_after >= 2) wait_vm_lgkm_and_barrier<(ST >= 4 ? 2 * LOADS : 0)>();
         else if (ST >= 3 && tiles_after >= 1) wait_vm_lgkm_and_barrier<(ST >= 3 ? LOADS : 0)>();
         else wait_vm_lgkm_and_barrier<0>();
     };
-    E8 a0[MI], b0[NI], a1[MI], b1[NI];
+    E8 a0[MI], a1[MI];
+    BF b0[NI], b1[NI];
     {
         const int rem = nk - 1 - kt0;
         admit(rem < ST - 2 ? rem : ST - 2);
@@ -289,7 +342,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
             for (int j = 0; j < NI; ++j) *(f32x4*)(mine + ((i * NI + j) * NT + tid) * 4) = acc[i][j];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int* flag = (int*)(smem + ST * (BM + BN) * BK * (int)sizeof(E));     // first word of the prefetch scratch (unused until phase 2)
+        int* flag = (int*)(smem + RING_BYTES);     // first word of the prefetch scratch (unused until phase 2)
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -339,6 +392,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
                 const int n = n0 + lc;
                 if (n >= g.N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (W8) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) v[t] *= ws[t]; }
                 if (g.bias) { E4 b = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (rb) { E4 b = *(const E4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
@@ -358,6 +412,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
             for (int j = 0; j < NI; ++j) {
                 const int n = n0 + wn * WN + j * 16 + fq * 4;           // permuted column held by this lane
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (W8 && n < g.N) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) a[t] *= ws[t]; }
                 if (g.bias && n < g.N) { E4 ba = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) a[t] += (float)ba[t]; }
                 float b[4];
                 for (int t = 0; t < 4; ++t) b[t] = __shfl_xor(a[t], 32, 64);     // all lanes take part in the exchange
@@ -382,7 +437,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     auto touch_next_weights = [&]() {
         const int per = (g.pf_lines + (int)gridDim.x - 1) / (int)gridDim.x;
         const long l0 = (long)blockIdx.x * per, last = g.pf_lines - 1;
-        char* scratch = smem + ST * (BM + BN) * BK * (int)sizeof(E) + wave * 256;
+        char* scratch = smem + RING_BYTES + wave * 256;
 #pragma unroll
         for (int i = 0; i < PF_TOUCHES; ++i) {
             long l = l0 + min(tid + i * NT, per - 1);
@@ -480,12 +535,12 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA touches must land before the LDS is released
 }
 
-template <typename E, int BM, int BN, int ST, int WAVES_M = 2>
+template <typename E, int BM, int BN, int ST, int WAVES_M = 2, bool W8 = false>
 int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = ST * (BM + BN) * BK * sizeof(f16) + 1024;   // ring (reused as the output tile) + prefetch scratch
+    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 1024;   // ring (reused as the output tile) + prefetch scratch
     // pick the XCD partition (xm x 8/xm rectangles of the tile grid) with the least bytes each 4 MiB L2 pulls over the
     // fabric.  Inside a rectangle tiles walk M fastest, ~64 workgroups are resident per XCD, so its rm x BM rows of A are
     // re-used by successive groups of N-tile columns: if they fit the L2 they are read once, otherwise once per group.
@@ -505,6 +560,12 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
         if (best < 0. || cost < best) { best = cost; g.xm = xm; g.rm = rm; g.rn = rn; }
     }
     const dim3 grid(8 * g.rm * g.rn * (g.splitk == 2 ? 2 : 1)), block(128 * WAVES_M);
+    if constexpr (W8) {
+        static bool attr_8 = false;
+        if (!attr_8) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_8 = true; }
+        iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, grid, block, lds, stream, g);
+        return iir_launch_status();
+    } else
     if (conv) {
         static bool attr_c = false;
         if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
@@ -520,6 +581,12 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
 // fp16 build of every tile / ring depth; bf16 build (the VAE) of the two-stage tiles the chooser picks for it
 template <int BM, int BN, int ST, int WAVES_M = 2>
 int launch(const Geo& g, bool conv, hipStream_t stream) {
+    if (g.wscale) {           // fp8-weight build: fp16 activations, linear layers, the 4-wave tiles
+        if constexpr (WAVES_M == 2 && (ST == 2 || (ST == 3 && BM == 64 && BN == 160))) {
+            if (conv || g.dtype != IIR_DT_F16 || g.splitk == 2) return IIR_EINVAL;
+            return launch_t<f16, BM, BN, ST, WAVES_M, true>(g, false, stream);
+        } else return IIR_EINVAL;
+    }
     if (g.dtype == IIR_DT_BF16) {
         if constexpr (ST == 2 && WAVES_M == 2) return launch_t<bf16, BM, BN, ST, WAVES_M>(g, conv, stream);
         else return IIR_EINVAL;
@@ -650,6 +717,11 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     if (d->c_f32) {
         if (d->epi != IIR_EPI_PLAIN || d->bias || d->rowbias || d->res || d->Ct || d->act || d->ldc % 4 || (uintptr_t)d->C % 16 || d->splitk_ws) return IIR_EINVAL;
         g.c_f32 = 1;
+    }
+    if (d->wscale) {          // W is fp8-E4M3 [N][K] bytes with one fp32 scale per row of W
+        if (d->c_f32 || d->K % 64 || (uintptr_t)d->W % 16 || (uintptr_t)d->wscale % 16 || d->dtype != IIR_DT_F16) return IIR_EINVAL;
+        g.wscale = (const float*)d->wscale;
+        g.sk_slabs = nullptr;
     }
     if (d->Ct) {
         if (d->epi != IIR_EPI_PLAIN || d->tr_from < 0 || d->tr_from >= d->N || d->tr_from % 8 || d->ldct < d->M) return IIR_EINVAL;

@@ -130,10 +130,11 @@ class _RecDict(dict):
 class _Net:
     """Shared machinery: packed weights, arena, resnet / transformer executors."""
 
-    def __init__(self, cfg: UNetConfig, sd: Dict[str, torch.Tensor], cross: bool, device):
+    def __init__(self, cfg: UNetConfig, sd: Dict[str, torch.Tensor], cross: bool, device, fp8_linear: bool = False):
         self.cfg = cfg
         self.cross = cross
         self.device = device
+        self.fp8_linear = fp8_linear      # BASELINE configs[4]: transformer linears as fp8-E4M3 weights (iir_gemm_desc.wscale)
         self.arena = Arena(device)
         self.o = ops
         self.w: Dict[str, torch.Tensor] = {}
@@ -213,6 +214,13 @@ class _Net:
             self.w[p + ".ff1.w"] = pair_rows(w1[:n], w1[n:])          # GEGLU: value rows | gate rows
             self.w[p + ".ff1.b"] = pair_rows(b1[:n], b1[n:])
             self._pack_linear(sd, p + ".ff.net.2", p + ".ff2")
+            if self.fp8_linear:
+                for key in ([p + ".attn1.qkv.w", p + ".attn1.to_out.0.w", p + ".ff1.w", p + ".ff2.w"]
+                            + ([p + ".attn2.to_q.w", p + ".attn2.to_out.0.w"] if self.cross else [])):
+                    self.w[key] = ops.Fp8Weight(*ops.quantize_fp8_rows(self.w[key]))
+        if self.fp8_linear:
+            for key in (path + ".proj_in.w", path + ".proj_out.w"):
+                self.w[key] = ops.Fp8Weight(*ops.quantize_fp8_rows(self.w[key]))
 
     def _pack_encoder(self, sd):
         cfg = self.cfg
@@ -285,6 +293,7 @@ class _Net:
                 seen.add(k)
                 order.append(k)
         order += [k for k in self.w if k not in seen]
+        order = [k for k in order if torch.is_tensor(self.w[k]) and self.w[k].dtype == F16]      # (fp8 weights stay where they are)
         al = lambda n: (n + 127) // 128 * 128
         offs, tot = [], 0
         for k in order:
@@ -297,13 +306,7 @@ class _Net:
             v.copy_(t)
             self.w[k] = v
         self._warena = arena
-        n_used = len(seen)
-        bounds = marks + [n_used]
-        self.units = []
-        for a, b in zip(bounds[:-1], bounds[1:]):
-            lo = offs[a] if a < len(offs) else tot
-            hi = offs[b] if b < len(offs) else tot
-            self.units.append((arena.data_ptr() + 2 * lo, 2 * (hi - lo)))
+        self.units = [None]                 # (consolidated: `_size_arena` records the order of use only once)
         self._use_log = None
 
     def _unit(self, name):
@@ -488,10 +491,10 @@ class _Net:
 class HipUNet(_Net):
     """SDXL UNet with TA-IP cross-attention.  `lora`/`lora_scaling` build the previewer weight set."""
 
-    def __init__(self, cfg: UNetConfig, sd: Dict[str, torch.Tensor], device, lora=None, lora_scaling=1.0):
+    def __init__(self, cfg: UNetConfig, sd: Dict[str, torch.Tensor], device, lora=None, lora_scaling=1.0, fp8_linear=False):
         if lora is not None:
             sd = _merge_lora({k: v.to(device) for k, v in sd.items()}, {k: v.to(device) for k, v in lora.items()}, lora_scaling)
-        super().__init__(cfg, sd, True, device)
+        super().__init__(cfg, sd, True, device, fp8_linear=fp8_linear)
         skips = skip_channels(cfg)
         rev = list(reversed(cfg.block_out_channels))
         depth = list(reversed(cfg.transformer_depth))

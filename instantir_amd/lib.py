@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("Ct", C.c_void_p), ("ldct", C.c_int64), ("tr_from", C.c_int32),
         ("dtype", C.c_int32), ("c_f32", C.c_int32),
+        ("wscale", C.c_void_p),
     ]
 
 

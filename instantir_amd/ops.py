@@ -107,15 +107,53 @@ def splitk_workspace(M, N, device):
     return torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
 
 
+FP8_MAX = 448.0          # largest finite E4M3 (OCP) value
+
+
+class Fp8Weight:
+    """A linear layer's weight as fp8-E4M3 bytes + per-output-channel fp32 scale; `gemm` accepts it in place of `w`."""
+
+    def __init__(self, q, scale):
+        self.q, self.scale = q, scale
+        self.shape = q.shape
+
+    def numel(self):
+        return self.q.numel() // 2          # in fp16-element units: what the weight-arena bookkeeping counts
+
+    def data_ptr(self):
+        return self.q.data_ptr()
+
+
+def quantize_fp8_rows(w):
+    """Per-output-channel E4M3 quantisation of a weight matrix (N, K): returns (bytes (N, K) as torch.float8_e4m3fn,
+    fp32 scale (N,)) with w ~= bytes * scale[:, None].  Pack-time plumbing for `gemm(..., wscale=)`."""
+    w32 = w.float()
+    scale = (w32.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX).contiguous()
+    q = (w32 / scale[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).contiguous()
+    return q, scale
+
+
 def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
-         tile=0, prefetch=None, splitk_ws=None, out_t=None):
+         tile=0, prefetch=None, splitk_ws=None, out_t=None, wscale=None):
     """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues).
-    out_t = (Ct, tr_from): output columns >= tr_from go, transposed, to Ct[n - tr_from, m]; `out` then is (M, tr_from)."""
+    out_t = (Ct, tr_from): output columns >= tr_from go, transposed, to Ct[n - tr_from, m]; `out` then is (M, tr_from).
+    wscale (fp32 (N,)): `w` holds fp8-E4M3 bytes (torch.float8_e4m3fn / uint8) with that per-row scale (fp8 MFMA)."""
     dt = a.dtype
+    if isinstance(w, Fp8Weight):
+        w, wscale = w.q, w.scale
+    if wscale is not None:
+        if w.dtype not in (torch.float8_e4m3fn, torch.uint8) or w.dim() != 2 or not w.is_contiguous() or not w.is_cuda:
+            raise ValueError("fp8 weights: contiguous 2-D CUDA tensor of torch.float8_e4m3fn (or its bytes)")
+        if wscale.dtype != torch.float32 or wscale.numel() != w.shape[0] or not wscale.is_contiguous():
+            raise ValueError("wscale: contiguous fp32 (N,)")
+        if dt != torch.float16:
+            raise ValueError("fp8 weights take fp16 activations")
     if dt not in _DT:
         raise ValueError(f"a: fp16 or bf16 expected, got {dt}")
     c_f32 = out.dtype == torch.float32                 # fp32 output (plain epilogue only): the VAE's attention scores
-    _chk2d(a, "a", dt); _chk2d(w, "w", dt); _chk2d(out, "out", torch.float32 if c_f32 else dt)
+    _chk2d(a, "a", dt); _chk2d(out, "out", torch.float32 if c_f32 else dt)
+    if wscale is None:
+        _chk2d(w, "w", dt)
     for t_, n_ in ((bias, "bias"), (rowbias, "rowbias"), (res, "res")):
         if t_ is not None and t_.dtype != dt:
             raise ValueError(f"{n_}: dtype {t_.dtype} does not match the operands ({dt})")
@@ -140,6 +178,8 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
         d.res, d.ldr = res.data_ptr(), res.stride(0)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
     d.dtype, d.c_f32 = _DT[dt], int(c_f32)
+    if wscale is not None:
+        d.wscale = wscale.data_ptr()
     if tile == 0:       # the library decides; resolve the same choice here only to NAME the launch for the profiler
         tile = 4 if splitk_ws is not None and L.load().iir_gemm_uses_splitk(M, N, K, splitk_ws.numel()) else auto_tile(M, N, epi != EPI_PLAIN, K)
     if prefetch is not None:
@@ -153,8 +193,8 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
             raise ValueError("out_t must hold (N - tr_from, M)")
         d.Ct, d.ldct, d.tr_from = ct.data_ptr(), ct.stride(0), tr_from
     No = N // 2 if epi != EPI_PLAIN else N
-    with _Timed("gemm_kernel<%s,gemm>" % _TILE_NAMES[tile % 10], 2.0 * M * N * K,
-                2.0 * (M * K + N * K + M * No + (M * No if res is not None else 0))):
+    with _Timed("gemm_kernel<%s,%s>" % (_TILE_NAMES[tile % 10], "gemm" if wscale is None else "gemm-w8"), 2.0 * M * N * K,
+                2.0 * (M * K + N * K * (1.0 if wscale is None else 0.5) + M * No + (M * No if res is not None else 0))):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out
 

@@ -307,14 +307,23 @@ class InstantIRPipeline:
     @torch.no_grad()
     def restore_single_step(self, image, prompt_embeds, pooled_prompt_embeds, ip_adapter_image_embeds=None,
                             ip_adapter_image=None, timestep: int = 999, previewer_scheduler=None, generator=None,
-                            init_noise=None, output_type: str = "pil", **kwargs):
+                            init_noise=None, output_type: str = "pil", fp8: bool = False, **kwargs):
         """LCM one-step restoration with the previewer LoRA, no CFG (guidance 1.0): noise the LQ latent to `timestep`
         (`prepare_latents` there = scheduler.add_noise), ONE UNet pass with the LoRA enabled, `LCMSingleStepScheduler.step`
-        (schedulers/lcm_single_step_scheduler.py:421-489), VAE decode."""
+        (schedulers/lcm_single_step_scheduler.py:421-489), VAE decode.  `fp8=True` (BASELINE configs[4]): the transformer
+        blocks' linear layers of that pass run on fp8-E4M3 weights (per-output-channel scales, activations converted in the
+        GEMM, `v_mfma_f32_16x16x32_fp8_fp8`) -- a third weight set, built on first use; its tolerance is its own."""
         from .engine import CPAD, F16
-        self._build()
-        if self._unet_prev is None:
+        if self._lora is None:
             raise RuntimeError("restore_single_step needs the previewer LoRA: call prepare_previewers(...)")
+        if fp8:
+            if getattr(self, "_unet_prev8", None) is None:
+                self._unet_prev8 = HipUNet(self.cfg, self._unet_sd, self.device, lora=self._lora, lora_scaling=self._lora_scaling,
+                                           fp8_linear=True)
+            net = self._unet_prev8
+        else:
+            self._build()
+            net = self._unet_prev
         sched = previewer_scheduler if previewer_scheduler is not None else LCMSingleStepScheduler.from_config(self.scheduler.config)
         dev, cfg = self.device, self.cfg
         image = self._prepare_image(image)
@@ -328,7 +337,7 @@ class InstantIRPipeline:
             ip_adapter_image_embeds = self.prepare_ip_adapter_image_embeds(ip_adapter_image, False)
         px = (Hl * self.vae_scale_factor, Wl * self.vae_scale_factor)
         time_ids = torch.tensor([[px[0], px[1], 0, 0, px[0], px[1]]], dtype=torch.float32).repeat(B, 1)
-        st = self._unet_prev.prepare(prompt_embeds, pooled_prompt_embeds, time_ids, self._unet_prev.resampler(ip_adapter_image_embeds[0]), Hl, Wl)
+        st = net.prepare(prompt_embeds, pooled_prompt_embeds, time_ids, net.resampler(ip_adapter_image_embeds[0]), Hl, Wl)
         if init_noise is None:
             gdev = generator.device if generator is not None else dev
             init_noise = torch.randn(lq.shape, generator=generator, device=gdev, dtype=torch.float32)
@@ -336,7 +345,7 @@ class InstantIRPipeline:
         lat16 = torch.zeros(B * Hl * Wl, CPAD, dtype=F16, device=dev)
         ops.pack_latent(x, lat16)
         t_dev = torch.full((B, 1), float(timestep), dtype=torch.float32, device=dev)
-        eps = self._unet_prev.forward(lat16, t_dev, st)
+        eps = net.forward(lat16, t_dev, st)
         out16 = torch.zeros(B * Hl * Wl, CPAD, dtype=F16, device=dev)
         out = torch.empty(B, 4, Hl, Wl, dtype=torch.float32, device=dev)
         coef = torch.tensor(sched.preview_coefficients(timestep), dtype=torch.float32).to(dev)

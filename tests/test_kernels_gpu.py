@@ -411,3 +411,47 @@ def test_pointwise(dev):
     assert torch.equal(t[:, :40].cpu(), x.T) and t[:, 40:].abs().max().item() == 0
 
 
+
+
+@pytest.mark.parametrize("M,N,K,mode,tile", [(256, 320, 640, "plain", 0), (300, 132, 128, "plain", 2), (2048, 1280, 1280, "plain", 0),
+                                              (2048, 1280, 1280, "plain", 24), (512, 1280, 640, "geglu", 0), (130, 96, 256, "geglu", 3),
+                                              (256, 3 * 128, 128, "qkv", 0), (1024, 640, 1280, "plain", 5), (64, 64, 64, "plain", 1)])
+def test_gemm_fp8_weights(dev, M, N, K, mode, tile):
+    """`wscale=`: fp8-E4M3 weights with per-output-channel scales, activations converted to fp8 inside the kernel
+    (v_mfma_f32_16x16x32_fp8_fp8).  Reference: the SAME quantised operands (torch's E4M3 casts) multiplied in fp32 -- this
+    isolates the kernel (layout, k order of the packed conversions, scale / bias / residual / GEGLU / transposed epilogues)
+    from the quantisation error itself, which is configs[4]'s own tolerance (tests/test_pipeline_gpu.py)."""
+    from instantir_amd import ops
+    from instantir_amd.packing import pair_rows
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _rand(g, M, K) * 1.5
+    w, b = _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
+    xq = x.to(torch.float8_e4m3fn).float()
+    if mode == "geglu":
+        wp, bp = pair_rows(w[:N // 2], w[N // 2:]), pair_rows(b[:N // 2], b[N // 2:])
+        q, sc = ops.quantize_fp8_rows(wp)
+        full = xq @ (q.float() * sc[:, None]).T + bp.float()
+        # paired rows: in every 16-row group the first 8 are values, the next 8 their gates
+        v = full.reshape(M, N // 16, 2, 8)
+        want = (v[:, :, 0] * F.gelu(v[:, :, 1])).reshape(M, N // 2)
+        out = torch.empty(M, N // 2, dtype=torch.half, device=dev)
+        ops.gemm(x.to(dev), q.to(dev), out, bias=bp.to(dev), epi=ops.EPI_GEGLU, tile=tile, wscale=sc.to(dev))
+        torch.cuda.synchronize()
+        _close(out, want, rtol=4e-3, atol=4e-3, what="fp8 GEGLU")
+        return
+    q, sc = ops.quantize_fp8_rows(w)
+    full = xq @ (q.float() * sc[:, None]).T
+    if mode == "qkv":
+        C = N // 3
+        qk = torch.empty(M, 2 * C, dtype=torch.half, device=dev)
+        vt = torch.empty(C, M, dtype=torch.half, device=dev)
+        ops.gemm(x.to(dev), q.to(dev), qk, out_t=(vt, 2 * C), tile=tile, wscale=sc.to(dev))
+        torch.cuda.synchronize()
+        _close(qk, full[:, :2 * C], rtol=4e-3, atol=4e-3, what="fp8 q|k")
+        _close(vt, full[:, 2 * C:].T, rtol=4e-3, atol=4e-3, what="fp8 V^T")
+        return
+    res = _rand(g, M, N)
+    out = torch.empty(M, N, dtype=torch.half, device=dev)
+    ops.gemm(x.to(dev), q.to(dev), out, bias=b.to(dev), res=res.to(dev), tile=tile, wscale=sc.to(dev))
+    torch.cuda.synchronize()
+    _close(out, full + b.float() + res.float(), rtol=4e-3, atol=4e-3, what="fp8 gemm")

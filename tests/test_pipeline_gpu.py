@@ -290,3 +290,29 @@ def test_ip_adapter_image_defaults_to_image_and_preview_row(env):
     want = _call(pipe, inp, num_inference_steps=3, guidance_scale=5.0, preview_end=0.7)
     assert psnr(out.float().cpu(), want) >= 70
     assert len(row) == 2 and all(r.shape == inp["lq"].shape for r in row)     # steps 0 and 1 preview, step 2 does not
+
+
+def test_single_step_previewer_restoration_fp8(env):
+    """BASELINE configs[4]: the same single LCM step with the transformer linears on fp8-E4M3 weights.  Its tolerance is its
+    own (8-bit operands with 3 mantissa bits; the reference has no fp8 path to compare with): asserted against the fp32
+    oracle at >= 20 dB and against the fp16 HIP path at >= 20 dB; measured values go to gpurun_out/psnr.log."""
+    from instantir_amd.schedulers import DDPMScheduler
+    from oracle import nets, sched
+    cfg, sd, sda, lora, inp = env
+    pipe = _pipe(cfg, sd, sda, lora, DDPMScheduler())
+    feats = inp["img"][1:]
+    kw = dict(ip_adapter_image_embeds=[feats], init_noise=inp["init_noise"], output_type="latent")
+    got8 = pipe.restore_single_step(inp["lq"], inp["pe"], inp["pooled"], fp8=True, **kw).images.float().cpu()
+    got16 = pipe.restore_single_step(inp["lq"], inp["pe"], inp["pooled"], **kw).images.float().cpu()
+    P = {k: v.float() for k, v in sd.items()}
+    L = {k: v.float() for k, v in lora.items()}
+    L["scaling"] = 16.0 / cfg.lora_rank
+    acp = sched.make_alphas_cumprod()
+    B = inp["B"]
+    x = sched.add_noise(acp, inp["lq"], inp["init_noise"], [999] * B)
+    tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]]).repeat(B, 1)
+    ip = nets.image_projection(P, [feats], cfg.resampler, L)[0]
+    want = sched.lcm_step(acp, nets.unet_forward(P, cfg, x, 999, inp["pe"], inp["pooled"], tid, ip, lora=L), 999, x)
+    p_oracle, p_16 = psnr(got8, want), psnr(got8, got16)
+    assert torch.isfinite(got8).all() and p_oracle >= 20 and p_16 >= 20, (p_oracle, p_16)
+    assert not torch.equal(got8, got16)                      # the fp8 weight set is really in use

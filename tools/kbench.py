@@ -30,6 +30,12 @@ def gemm_bench():
         for tile in TILES:
             t = timeit(lambda: ops.gemm(a, w, outg, tile=tile, epi=ops.EPI_GEGLU) if geglu else ops.gemm(a, w, out, tile=tile))
             row += f"  t{tile} {2*M*N*K/t/1e12:6.0f}"
+        if os.environ.get("W8", "0") == "1":          # the same launches on fp8-E4M3 weights
+            w8 = ops.Fp8Weight(*ops.quantize_fp8_rows(w))
+            row += "  | fp8-w:"
+            for tile in TILES:
+                t = timeit(lambda: ops.gemm(a, w8, outg, tile=tile, epi=ops.EPI_GEGLU) if geglu else ops.gemm(a, w8, out, tile=tile))
+                row += f"  t{tile} {2*M*N*K/t/1e12:6.0f}"
         t = timeit(lambda: torch.matmul(a, w.T, out=out))
         row += f"  | hipblaslt {2*M*N*K/t/1e12:7.1f} TF"
         print(row, flush=True)
