@@ -66,6 +66,11 @@ def main():
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-inkernel-prefetch", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no encoder/previewer overlap)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 4],
+                    help="BASELINE.json configs index: 1 = the metric's own workload (default); 4 = LCM single-step previewer "
+                         "restoration, 4 images per GPU, fp8-E4M3 weights on the linear layers (a parity-test configuration, "
+                         "printed as its own line)")
+    ap.add_argument("--fp16", action="store_true", help="--config 4 with fp16 linears (A/B of the fp8 path)")
     args = ap.parse_args()
 
     # ---- launch contract: `--gpus N` must mean N ranks.  Under torch.distributed.run WORLD_SIZE says how many there are;
@@ -94,6 +99,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the denoising path has no CPU fallback")
     lib.load()
+    if args.config == 4:
+        return config4(args, rank, world, local, dev)
     cfg = UNetConfig.tiny() if args.tiny else UNetConfig.sdxl()
     Hl = args.size // 8
     B, guidance, n_steps_sched = 1, 7.0, 30
@@ -266,6 +273,111 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def config4(args, rank, world, local, dev):
+    """BASELINE configs[4]: LCM single-step scheduler, previewer-LoRA path, 32 images of 1024x1024 over 8 GPUs = 4 images per
+    GPU, guidance 1.0 (no CFG doubling), fp8 weights.  One "step" = the whole single-step restoration of the GPU's 4 images:
+    noise to t = 999, ONE LoRA-UNet pass (R = 4 rows; transformer linears on fp8-E4M3 weights), LCM x0 step.  VAE encode /
+    decode are once-per-image stages outside the step and are timed separately (bf16)."""
+    from instantir_amd import ops, parallel, weights as W
+    from instantir_amd.config import UNetConfig, VAEConfig
+    from instantir_amd.engine import CPAD, F16, HipUNet
+    from instantir_amd.schedulers import LCMSingleStepScheduler
+    cfg = UNetConfig.tiny() if args.tiny else UNetConfig.sdxl()
+    Hl, B, t999 = args.size // 8, 4, 999
+    seed = 1234
+    ranks_info = parallel.describe_ranks(rank, world, local, dev)
+    inv = [(W.unet_specs(cfg), seed), (W.lora_specs(cfg), seed + 2)]
+    if rank == 0:
+        sd, lora = (W.synth_state_dict(sp, sd_seed, device=dev) for sp, sd_seed in inv)
+    else:
+        sd, lora = ({n: torch.empty(shape, dtype=torch.float16, device=dev) for n, shape, _ in sp} for sp, _ in inv)
+    if world > 1:
+        for d in (sd, lora):
+            parallel.broadcast_state_dict(d, 0)
+    net = HipUNet(cfg, sd, dev, lora=lora, lora_scaling=(cfg.lora_rank // 8) / cfg.lora_rank, fp8_linear=not args.fp16)
+    del sd, lora
+    torch.cuda.empty_cache()
+    g = torch.Generator().manual_seed(42 + rank)
+    lq = (torch.randn(B, 4, Hl, Hl, generator=g) * 0.8).to(dev)
+    pe = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g)
+    pooled = torch.randn(B, cfg.pooled_dim, generator=g)
+    img = torch.randn(1, B, cfg.resampler.seq_len, cfg.resampler.embedding_dim, generator=g)
+    px = Hl * 8
+    time_ids = torch.tensor([[px, px, 0, 0, px, px]], dtype=torch.float32).repeat(B, 1)
+    st = net.prepare(pe, pooled, time_ids, net.resampler(img), Hl, Hl)
+    lcm = LCMSingleStepScheduler()
+    noise = torch.randn(B, 4, Hl, Hl, generator=g).to(dev)
+    coef = torch.tensor(lcm.preview_coefficients(t999), dtype=torch.float32).to(dev)
+    t_dev = torch.full((B, 1), float(t999), dtype=torch.float32, device=dev)
+    lat16 = torch.zeros(B * Hl * Hl, CPAD, dtype=F16, device=dev)
+    out16 = torch.zeros(B * Hl * Hl, CPAD, dtype=F16, device=dev)
+    out = torch.empty(B, 4, Hl, Hl, dtype=torch.float32, device=dev)
+
+    def step():
+        x = lcm.add_noise(lq, noise, torch.tensor([t999] * B)).contiguous()
+        ops.pack_latent(x, lat16)
+        eps = net.forward(lat16, t_dev, st)
+        ops.lcm_step(eps, B, 1, coef, x, out16, out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t1, dev)
+    finite = bool(torch.isfinite(out).all().item())
+    vae_ms = roof = None
+    if rank == 0 and not args.tiny and not args.no_vae:
+        from instantir_amd.vae import HipVAE
+        vc = VAEConfig.sdxl()
+        hv = HipVAE(vc, W.synth_state_dict(W.vae_decoder_specs(vc) + W.vae_encoder_specs(vc), seed + 3, device=dev), dev)
+        pimg = torch.rand(1, 3, px, px, generator=g) * 2 - 1
+        eps_l = torch.randn(1, 4, Hl, Hl, generator=g)
+        for _ in range(2):
+            hv.decode(out[:1] / vc.scaling_factor); hv.encode(pimg, eps_l)
+        torch.cuda.synchronize()
+        tv = time.perf_counter(); hv.decode(out[:1] / vc.scaling_factor); torch.cuda.synchronize(); dec_ms = (time.perf_counter() - tv) * 1e3
+        tv = time.perf_counter(); hv.encode(pimg, eps_l); torch.cuda.synchronize(); enc_ms = (time.perf_counter() - tv) * 1e3
+        vae_ms = {"decode_ms_per_image": round(dec_ms, 2), "encode_ms_per_image": round(enc_ms, 2)}
+        del hv
+    if rank == 0 and not args.no_roofline:
+        step()
+        ops.PROFILER = ops.LaunchProfiler()
+        torch.cuda._sleep(int(1.2e9))
+        step(); step()
+        summ = ops.PROFILER.summary()
+        ops.PROFILER = None
+        name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                "traffic": None, "peak_note": "v_mfma_f32_16x16x32_fp8_fp8 (non-scaled) issues at the fp16/bf16 rate (MI355X_MICROARCH.md); the "
+                                              "5 PFLOP/s fp8 figure belongs to the MX block-scaled K = 128 form, which this path does not use",
+                "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches_per_step": d["launches"] // 2,
+                "classes": {k: {"launches_per_step": v["launches"] // 2, "ms_per_step": round(v["ms"] / 2, 3),
+                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in sorted(summ.items())}}
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        per_img_s = ms * 1e-3 / B + ((vae_ms or {}).get("decode_ms_per_image", 0) + (vae_ms or {}).get("encode_ms_per_image", 0)) * 1e-3
+        print(json.dumps({
+            "metric": "restoration steps/sec, LCM single-step previewer path at 1024x1024 (BASELINE configs[4]; not the headline metric)",
+            "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp8-e4m3 weights + in-kernel fp8 activations on the transformer linears (fp32 accumulate); fp16 elsewhere" if not args.fp16 else "f16 (fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: LCM single step (t = 999, guidance 1.0), previewer LoRA merged, {B} images/GPU at "
+                                   f"{args.size}x{args.size}, one UNet pass of {B} rows + LCM step per step" + (" [TINY DEBUG GEOMETRY]" if args.tiny else ""),
+                       "images_per_gpu": B, "images_per_s_incl_vae": round(world / per_img_s, 3), "vae": vae_ms, "finite": finite,
+                       "algorithmic_tflop_per_step": round(6.833 * B, 2), "algorithmic_tflops_per_gpu": round(6.833 * B / (ms * 1e-3), 1),
+                       "world": world, "ranks": ranks_info},
+            "roofline": roof, "cpu_baseline": None}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
