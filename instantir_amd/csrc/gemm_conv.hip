@@ -595,7 +595,7 @@ int launch(const Geo& g, bool conv, hipStream_t stream) {
 }
 
 struct TileShape { int bm, bn; };
-constexpr TileShape kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}, {256, 128}, {128, 320}, {256, 256}};
+constexpr TileShape kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}, {256, 128}, {128, 320}, {256, 256}, {32, 160}};
 
 // Tile choice: the per-CU operand fill rate (L2 -> LDS, ~50-70 GB/s) bounds these launches, so pick the
 // shape that minimises the bytes the busiest CU has to pull.  Two workgroups per CU overlap each other's
@@ -672,6 +672,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         case 42: return launch<128, 64, 4>(g, conv, stream);
         case 26: return launch<256, 128, 2, 4>(g, conv, stream);   // 8 waves, 1 workgroup per CU
         case 36: return launch<256, 128, 3, 4>(g, conv, stream);
+        case 29: return launch<32, 160, 2>(g, conv, stream);       // 512 workgroups on a 2048 x 1280 problem: two per CU, 24 KB per K tile each
         case 27: return launch<128, 320, 2, 4>(g, conv, stream);   // 8 waves (4 x 2), 56 KB of operands per K tile: 91 FLOP per staged byte
         case 28:                                                   // 8 waves, 64 KB per K tile: 128 FLOP per staged byte; the output tile
             if (g.epi == IIR_EPI_PLAIN && !g.c_f32) return IIR_EINVAL;   //   only fits the ring in its paired (half-width) form
@@ -689,7 +690,7 @@ void finish_geo(Geo& g) {
 
 }  // namespace
 
-extern "C" int iir_gemm_tile_bn(int32_t tile) { tile %= 10; return (tile >= 1 && tile <= 8) ? kTiles[tile].bn : -1; }
+extern "C" int iir_gemm_tile_bn(int32_t tile) { tile %= 10; return (tile >= 1 && tile <= 9) ? kTiles[tile].bn : -1; }
 
 extern "C" int64_t iir_gemm_splitk_workspace_bytes(int32_t M, int32_t N) { return splitk_ws_bytes(M, N); }
 extern "C" int iir_gemm_uses_splitk(int32_t M, int32_t N, int32_t K, int64_t ws_bytes) { return uses_splitk(M, N, K, ws_bytes) ? 1 : 0; }
