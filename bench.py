@@ -232,8 +232,15 @@ def main():
             if pm:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pm[-1])) as f:
                     traffic = json.load(f)["classes"].get(name, {}).get("hbm_bytes_per_launch")
+        mfma_busy = None
+        if not args.tiny and args.size == 1024:
+            pb = sorted(p_ for p_ in os.listdir(pdir) if p_.endswith("_pmc_mfma_busy.json")) if os.path.isdir(pdir) else []
+            if pb:
+                with open(os.path.join(pdir, pb[-1])) as f:
+                    mfma_busy = json.load(f)["classes"].get(name, {}).get("mfma_busy_frac")
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(ach / 2500.0, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)",
+                "mfma_busy_pmc": mfma_busy,      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), separate PMC pass (profiles/)
                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "launches_per_step": d["launches"] // 2,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "timing": "hipExtLaunchKernelGGL start/stop events (kernel begin/end timestamps)",
                 "classes": {k: {"launches_per_step": v["launches"] // 2, "ms_per_step": round(v["ms"] / 2, 3),

@@ -8,9 +8,12 @@ exact for 16 B/lane stores.  Both kernels' operand reads (LDS-DMA dwordx4) and s
 import csv, json, re, sys, collections
 
 def cls_of(name):
-    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (true|false)", name)
+    m = re.search(r"gemm_kernel<(?:[A-Za-z_0-9]+, )?(\d+), (\d+), (\d+), (true|false)", name)
     if m:
         return "gemm_kernel<%sx%s,%s>" % (m.group(1), m.group(2), "conv" if m.group(4) == "true" else "gemm")
+    m = re.search(r"gemm_kernelI(?:DF16_|DF16b)?Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)", name)          # mangled form
+    if m:
+        return "gemm_kernel<%sx%s,%s>" % (m.group(1), m.group(2), "conv" if m.group(4) == "1" else "gemm")
     if "attn_kernel" in name:
         return "attn_kernel"
     return None
