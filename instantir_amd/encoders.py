@@ -148,6 +148,128 @@ def dinov2_preprocess(images, size=256, crop=224, mean=(0.485, 0.456, 0.406), st
     return torch.from_numpy(np.stack(out)).permute(0, 3, 1, 2).contiguous()
 
 
+def clip_preprocess(images, size=224, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)):
+    """`CLIPImageProcessor()` with its defaults (module/ip_adapter/utils.py:114-118): bicubic resize of the shortest edge to
+    224, centre crop 224, rescale 1/255, CLIP normalise.  PIL in, fp32 NCHW out."""
+    return dinov2_preprocess(images, size=size, crop=size, mean=mean, std=std)
+
+
+class HipCLIPVision:
+    """CLIP vision tower (transformers `CLIPVisionModelWithProjection`, third-party) for the reference's `use_clip_encoder`
+    branch (`module/ip_adapter/utils.py:106-118`).  With a Resampler as the image projector the pipeline asks for
+    `hidden_states[-2]` of the image and of `zeros_like(image)` (`pipelines/sdxl_instantir.py:696-699,644-654`); `image_embeds`
+    (post-LayerNorm CLS feature through `visual_projection`) is provided as well (:656-659).
+
+    Patch conv without bias + class embedding + learned position table (fixed geometry), `pre_layrnorm` (sic, the HF
+    parameter name), pre-LN blocks with unmasked attention, quick-GELU or GELU MLP.  Token rows are padded to a multiple
+    of 8 (257 -> 264, pad keys masked).  Heads of dim 64 only (ViT-B/16, ViT-B/32, ViT-L/14): the attention kernel is a
+    d = 64 kernel, so ViT-H/14 (d = 80) and bigG (d = 104) are refused with that reason."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device, patch_size=None, num_heads=None, eps=1e-5, hidden_act="quick_gelu"):
+        self.device = torch.device(device)
+        dev = self.device
+        sd = {(k[len("vision_model."):] if k.startswith("vision_model.") else k): v for k, v in sd.items()}
+        f32 = lambda n: sd[n].to(dev, torch.float32)
+        wp = f32("embeddings.patch_embedding.weight")                    # (D, 3, p, p), no bias
+        self.D = D = wp.shape[0]
+        self.patch = wp.shape[-1] if patch_size is None else patch_size
+        self.heads = num_heads if num_heads is not None else D // 64
+        if D // self.heads != 64:
+            raise ValueError(f"HipCLIPVision: head_dim {D // self.heads} -- the attention kernel is built for head_dim 64 "
+                             "(CLIP ViT-B / ViT-L); ViT-H/14 and bigG towers are not supported")
+        kp = wp[0].numel()
+        self.kpad = (kp + 63) // 64 * 64
+        self.act = {"quick_gelu": ops.ACT_QUICKGELU, "gelu": ops.ACT_GELU}[hidden_act]
+        self.eps = eps
+        w = self.w = {}
+        w["patch.w"] = torch.nn.functional.pad(wp.reshape(D, kp), (0, self.kpad - kp)).to(F16).contiguous()
+        pos = f32("embeddings.position_embedding.weight")                # (1 + n^2, D)
+        self.n_pos = pos.shape[0]
+        w["pos"] = pos[1:].to(F16).contiguous()
+        w["cls"] = (f32("embeddings.class_embedding").reshape(D) + pos[0]).to(F16)
+        w["pre.g"], w["pre.b"] = f32("pre_layrnorm.weight").to(F16), f32("pre_layrnorm.bias").to(F16)
+        self.depth = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))
+        for i in range(self.depth):
+            p = f"encoder.layers.{i}"
+            a = p + ".self_attn"
+            w[f"{i}.n1.g"], w[f"{i}.n1.b"] = f32(p + ".layer_norm1.weight").to(F16), f32(p + ".layer_norm1.bias").to(F16)
+            w[f"{i}.n2.g"], w[f"{i}.n2.b"] = f32(p + ".layer_norm2.weight").to(F16), f32(p + ".layer_norm2.bias").to(F16)
+            w[f"{i}.qk.w"] = torch.cat([f32(a + ".q_proj.weight"), f32(a + ".k_proj.weight")]).to(F16).contiguous()
+            w[f"{i}.qk.b"] = torch.cat([f32(a + ".q_proj.bias"), f32(a + ".k_proj.bias")]).to(F16).contiguous()
+            w[f"{i}.v.w"] = f32(a + ".v_proj.weight").to(F16).contiguous()
+            wo = f32(a + ".out_proj.weight")
+            w[f"{i}.o.w"] = wo.to(F16).contiguous()
+            w[f"{i}.o.b"] = (wo @ f32(a + ".v_proj.bias") + f32(a + ".out_proj.bias")).to(F16).contiguous()   # value bias folded
+            w[f"{i}.fc1.w"], w[f"{i}.fc1.b"] = f32(p + ".mlp.fc1.weight").to(F16).contiguous(), f32(p + ".mlp.fc1.bias").to(F16)
+            w[f"{i}.fc2.w"], w[f"{i}.fc2.b"] = f32(p + ".mlp.fc2.weight").to(F16).contiguous(), f32(p + ".mlp.fc2.bias").to(F16)
+        w["post.g"], w["post.b"] = f32("post_layernorm.weight").to(F16), f32("post_layernorm.bias").to(F16)
+        self.proj = sd["visual_projection.weight"].to(dev, F16).contiguous() if "visual_projection.weight" in sd else None
+        self._zero_cache = {}
+
+    @torch.no_grad()
+    def forward(self, pixel_values: torch.Tensor, with_embeds: bool = False):
+        """pixel_values (B, 3, H, W) normalised (CLIPImageProcessor).  Returns hidden_states[-2] (B, 1 + (H/p)(W/p), D) fp16
+        [and image_embeds (B, P) when `with_embeds`]."""
+        dev, D, ps, w = self.device, self.D, self.patch, self.w
+        x = pixel_values.to(dev, torch.float32)
+        B, _, H, W = x.shape
+        gh, gw = H // ps, W // ps
+        T = 1 + gh * gw
+        if T != self.n_pos:
+            raise ValueError(f"CLIP vision tower has a fixed position table of {self.n_pos} tokens; a {H}x{W} input gives {T}")
+        Tp = (T + 7) // 8 * 8
+        M = B * Tp
+        pt = x[:, :, :gh * ps, :gw * ps].reshape(B, 3, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, 3 * ps * ps)
+        patches = torch.zeros(B * gh * gw, self.kpad, dtype=F16, device=dev)
+        patches[:, :3 * ps * ps] = pt.to(F16)
+        e = torch.zeros(M, D, dtype=F16, device=dev)
+        e3 = e.view(B, Tp, D)
+        e3[:, 0] = w["cls"]
+        for b in range(B):                                               # patch projection (no bias) + position rows
+            ops.gemm(patches[b * gh * gw:(b + 1) * gh * gw], w["patch.w"], e3[b, 1:T], res=w["pos"])
+        h = torch.empty(M, D, dtype=F16, device=dev)
+        ops.layernorm(e, h, w["pre.g"], w["pre.b"], self.eps)             # hidden_states[0]
+        n = torch.empty(M, D, dtype=F16, device=dev)
+        qk = torch.empty(M, 2 * D, dtype=F16, device=dev)
+        vt = torch.empty(D, M, dtype=F16, device=dev)
+        a = torch.empty(M, D, dtype=F16, device=dev)
+        f = torch.empty(M, w["0.fc1.w"].shape[0], dtype=F16, device=dev)
+        penult = None
+        for i in range(self.depth if with_embeds else self.depth - 1):   # hidden_states[-2] is the INPUT of the last layer
+            if i == self.depth - 1:
+                penult = h.clone()
+            ops.layernorm(h, n, w[f"{i}.n1.g"], w[f"{i}.n1.b"], self.eps)
+            ops.gemm(n, w[f"{i}.qk.w"], qk, bias=w[f"{i}.qk.b"])
+            ops.gemm(w[f"{i}.v.w"], n, vt)
+            ops.attention(qk[:, :D], a, [(qk[:, D:], Tp, vt, Tp, T)], B, self.heads, Tp)
+            ops.gemm(a, w[f"{i}.o.w"], h, bias=w[f"{i}.o.b"], res=h)
+            ops.layernorm(h, n, w[f"{i}.n2.g"], w[f"{i}.n2.b"], self.eps)
+            ops.gemm(n, w[f"{i}.fc1.w"], f, bias=w[f"{i}.fc1.b"], act=self.act)
+            ops.gemm(f, w[f"{i}.fc2.w"], h, bias=w[f"{i}.fc2.b"], res=h)
+        if not with_embeds:
+            return h.view(B, Tp, D)[:, :T]
+        if self.proj is None:
+            raise ValueError("image_embeds need `visual_projection.weight` (a CLIPVisionModelWithProjection state dict)")
+        rows8 = torch.zeros((B + 7) // 8 * 8, D, dtype=F16, device=dev)
+        rows8[:B] = h.view(B, Tp, D)[:, 0]                                # pooled = CLS row
+        pn = torch.empty_like(rows8)
+        ops.layernorm(rows8, pn, w["post.g"], w["post.b"], self.eps)
+        out = torch.empty(rows8.shape[0], self.proj.shape[0], dtype=F16, device=dev)
+        ops.gemm(pn, self.proj, out)
+        return penult.view(B, Tp, D)[:, :T], out[:B]
+
+    __call__ = forward
+
+    def encode_image_pair(self, pixel_values: torch.Tensor):
+        """`encode_image(..., output_hidden_states=True)` (pipelines/sdxl_instantir.py:644-654): penultimate hidden states of
+        the image and of `zeros_like(image)` (input independent, cached per geometry)."""
+        feats = self.forward(pixel_values)
+        key = tuple(pixel_values.shape[1:])
+        if key not in self._zero_cache:
+            self._zero_cache[key] = self.forward(torch.zeros(1, *key))
+        return feats, self._zero_cache[key].expand(pixel_values.shape[0], -1, -1)
+
+
 class HipCLIPText:
     """CLIP text transformer (transformers `CLIPTextModel` / `CLIPTextModelWithProjection`, third-party) as used by
     `encode_prompt` (pipelines/sdxl_instantir.py:400-632): SDXL takes `hidden_states[-2]` of both encoders (768 + 1280

@@ -127,8 +127,6 @@ def build_pipeline(args, device):
     from .pipeline import InstantIRPipeline
     from .schedulers import DDPMScheduler, LCMSingleStepScheduler
     from .vae import HipVAE
-    if args.use_clip_encoder:
-        raise NotImplementedError("--use_clip_encoder: only the DINOv2 image encoder branch is built")
     if args.synthetic:
         cfg = UNetConfig.tiny() if args.synthetic == "tiny" else UNetConfig.sdxl()
         vc = VAEConfig.tiny() if args.synthetic == "tiny" else VAEConfig.sdxl()

@@ -217,10 +217,10 @@ def load_adapter_to_pipe(pipe, pretrained_model_path_or_dict, image_encoder_or_p
                          use_clip_encoder=False, adapter_tokens=64, use_lcm=False, use_adaln=True):
     """`module/ip_adapter/utils.py:73-161` for this build's pipeline: installs the TA-IP processors + Resampler into the UNet
     state (the nets are packed lazily, at the first call) and attaches the DINOv2 image encoder (a `HipDinov2`, or a
-    directory holding `model.safetensors` / `pytorch_model.bin` [+ config.json]).  `feature_extractor_or_path` is accepted
-    and ignored: the fixed DINOv2 preprocessing lives in `encoders.dinov2_preprocess`."""
-    if use_clip_encoder:
-        raise NotImplementedError("use_clip_encoder: only the DINOv2 image-encoder branch is built")
+    directory holding `model.safetensors` / `pytorch_model.bin` [+ config.json]); with `use_clip_encoder=True` the directory
+    is read as a CLIP vision tower (`encoders.HipCLIPVision`, whose penultimate hidden states feed the Resampler).
+    `feature_extractor_or_path` is accepted and ignored: the fixed preprocessing lives in `encoders.dinov2_preprocess` /
+    `encoders.clip_preprocess`."""
     if not use_adaln:
         raise NotImplementedError("use_adaln=False (IPAttnProcessor2_0 without AdaLayerNorm) is not built")
     ad = read_adapter(pretrained_model_path_or_dict)
@@ -230,19 +230,27 @@ def load_adapter_to_pipe(pipe, pretrained_model_path_or_dict, image_encoder_or_p
     pipe.cfg = dataclasses.replace(pipe.cfg, resampler=rc, num_ip_tokens=rc.num_queries)
     pipe._unet_sd = install_adapter(pipe.cfg, pipe._unet_sd, ad)
     pipe._unet = pipe._unet_prev = None
+    pipe._prev_nets = {}
+    pipe._unet_prev8 = None
     if image_encoder_or_path is not None:
         if isinstance(image_encoder_or_path, str):
-            from .encoders import HipDinov2
+            from .encoders import HipCLIPVision, HipDinov2
             cands = [os.path.join(image_encoder_or_path, n) for n in ("model.safetensors", "pytorch_model.bin")]
             found = [c for c in cands if os.path.exists(c)]
             if not found:
                 raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {image_encoder_or_path}")
             kw = {}
             cj = os.path.join(image_encoder_or_path, "config.json")
-            if os.path.isfile(cj):
-                c = _read_json(cj)
-                kw = {"patch_size": c.get("patch_size", 14), "num_heads": c.get("num_attention_heads"), "eps": c.get("layer_norm_eps", 1e-6)}
-            pipe.image_encoder = HipDinov2(_load_file(found[0]), pipe.device, **kw)
+            c = _read_json(cj) if os.path.isfile(cj) else {}
+            if use_clip_encoder:          # CLIPVisionModelWithProjection.from_pretrained (module/ip_adapter/utils.py:106-112)
+                c = c.get("vision_config", c)
+                pipe.image_encoder = HipCLIPVision(_load_file(found[0]), pipe.device, patch_size=c.get("patch_size", 14),
+                                                   num_heads=c.get("num_attention_heads"), eps=c.get("layer_norm_eps", 1e-5),
+                                                   hidden_act=c.get("hidden_act", "quick_gelu"))
+            else:
+                if c:
+                    kw = {"patch_size": c.get("patch_size", 14), "num_heads": c.get("num_attention_heads"), "eps": c.get("layer_norm_eps", 1e-6)}
+                pipe.image_encoder = HipDinov2(_load_file(found[0]), pipe.device, **kw)
         else:
             pipe.image_encoder = image_encoder_or_path
     return pipe

@@ -78,6 +78,35 @@ class _AggregatorHandle:
         return out
 
 
+class _UNetHandle:
+    """The slice of `pipe.unet`'s peft surface the reference's callers touch: `set_adapter` / `active_adapters`
+    (gradio_demo/app.py:116-120 switches between the `previewer` and `lcm` LoRAs per request), `enable_adapters` /
+    `disable_adapters` (pipelines/sdxl_instantir.py:396, :1543, :1556).  Each adapter is a merged second weight copy built on
+    first use and kept (5 GB at SDXL size); switching adapters swaps which copy the previewer pass launches."""
+
+    def __init__(self, pipe):
+        self._pipe = pipe
+
+    def active_adapters(self):
+        return [self._pipe._active_adapter] if self._pipe._active_adapter is not None else []
+
+    def set_adapter(self, name):
+        if isinstance(name, (list, tuple)):
+            if len(name) != 1:
+                raise ValueError("one active LoRA adapter at a time (the reference's callers never mix them)")
+            name = name[0]
+        if name not in self._pipe._adapters:
+            raise ValueError(f"Adapter {name} not found. Available adapters: {list(self._pipe._adapters)}")
+        self._pipe._active_adapter = name
+        self._pipe._unet_prev = self._pipe._prev_nets.get((name, 1.0))
+
+    def enable_adapters(self):       # the loop itself decides which pass runs with the LoRA (:1543-1556)
+        pass
+
+    def disable_adapters(self):
+        pass
+
+
 class InstantIRPipeline:
     vae_scale_factor = 8
 
@@ -90,15 +119,17 @@ class InstantIRPipeline:
         self.device = torch.device(device)
         self._unet_sd = unet_state_dict
         self._agg_sd = aggregator_state_dict
-        self._lora = None
-        self._lora_scaling = 1.0
+        self._adapters = {}                          # name -> (peft-named LoRA tensors, alpha / r)
+        self._active_adapter = None
+        self._prev_nets = {}                         # (adapter, cross_attention_kwargs["scale"]) -> merged previewer copy
+        self.unet = _UNetHandle(self)
         self.scheduler = scheduler if scheduler is not None else DDPMScheduler()
         self.aggregator = _AggregatorHandle(self)
         self.vae = vae
         self.image_encoder = image_encoder          # encoders.HipDinov2 (module/ip_adapter/utils.py:106-118)
         self.text_encoder, self.text_encoder_2 = text_encoder, text_encoder_2     # encoders.HipCLIPText
         self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2               # callables: list[str] -> (B,77) int64 ids
-        self._unet = self._unet_prev = self._agg = None
+        self._unet = self._unet_prev = self._agg = self._unet_prev8 = None
         self._graphs = {}
         self.use_graphs = True
         self.overlap_streams = True
@@ -149,6 +180,19 @@ class InstantIRPipeline:
         return self._guidance_scale
 
     @property
+    def _lora(self):
+        return self._adapters[self._active_adapter][0] if self._active_adapter is not None else None
+
+    @_lora.setter
+    def _lora(self, v):            # bench.py drops the host copies once the device copies exist
+        if v is None:
+            self._adapters = {k: (None, sc) for k, (_, sc) in self._adapters.items()}
+
+    @property
+    def _lora_scaling(self):
+        return self._adapters[self._active_adapter][1] if self._active_adapter is not None else 1.0
+
+    @property
     def do_classifier_free_guidance(self):
         # pipelines/sdxl_instantir.py:1050-1051 (time_cond_proj_dim is None for SDXL)
         return self._guidance_scale > 1
@@ -181,17 +225,28 @@ class InstantIRPipeline:
             raise ValueError("Loading adapter weights from state_dict led to unexpected keys not found in the model: "
                              f" {unexpected}. ")
         lora_alpha = 1 if lora_alpha is None else lora_alpha
-        self._lora = dict(lora_state_dict)
-        self._lora_scaling = lora_alpha / self.cfg.lora_rank          # peft: alpha / r with r = 64 (:376-381)
-        self._unet_prev = None
+        name = "lcm" if use_lcm else "previewer"                       # :383
+        self._adapters[name] = (dict(lora_state_dict), lora_alpha / self.cfg.lora_rank)   # peft: alpha / r with r = 64 (:376-381)
+        for k in [k for k in self._prev_nets if k[0] == name]:
+            del self._prev_nets[k]
+        self._unet_prev8 = None
+        self.unet.set_adapter(name)        # diffusers' `add_adapter` ends in `set_adapter(adapter_name)`: the newest one is active
         return lora_alpha
 
     # ---- engine construction ----------------------------------------------------------------------
-    def _build(self):
+    def _build(self, lora_mult: float = 1.0):
+        """`lora_mult`: `cross_attention_kwargs["scale"]`, which diffusers' UNet forward turns into `scale_lora_layers(unet, scale)`
+        for the pass that runs with the adapters on -- i.e. the previewer copy is W + scale * (alpha / r) * B A."""
         if self._unet is None:
             self._unet = HipUNet(self.cfg, self._unet_sd, self.device)
-        if self._unet_prev is None and self._lora is not None:
-            self._unet_prev = HipUNet(self.cfg, self._unet_sd, self.device, lora=self._lora, lora_scaling=self._lora_scaling)
+        if self._active_adapter is not None:
+            key = (self._active_adapter, float(lora_mult))
+            if key not in self._prev_nets:
+                if self._lora is None:
+                    raise RuntimeError(f"LoRA adapter {self._active_adapter!r}: the host copy was released; call prepare_previewers again")
+                self._prev_nets[key] = HipUNet(self.cfg, self._unet_sd, self.device, lora=self._lora,
+                                               lora_scaling=self._lora_scaling * float(lora_mult))
+            self._unet_prev = self._prev_nets[key]
         if self._agg is None:
             if self._agg_sd is None:
                 self._agg_sd = self.aggregator.from_unet()
@@ -272,12 +327,15 @@ class InstantIRPipeline:
         return pe, npe, pooled, npooled
 
     def encode_image(self, image):
-        """`encode_image`, DINO branch (pipelines/sdxl_instantir.py:660-667): (features, zero-image features).
-        `image`: PIL image(s) (pre-processed like AutoImageProcessor of facebook/dinov2-*) or a normalised tensor."""
-        from .encoders import dinov2_preprocess
+        """`encode_image` (pipelines/sdxl_instantir.py:636-670): (features, zero-image features).  DINO branch (:660-667):
+        `last_hidden_state`; CLIP branch as `prepare_ip_adapter_image_embeds` calls it for a Resampler projector (:696-699,
+        :644-654): `hidden_states[-2]` of the image and of `zeros_like(image)`.
+        `image`: PIL image(s) (pre-processed like the encoder's own image processor) or a normalised tensor."""
+        from .encoders import HipCLIPVision, clip_preprocess, dinov2_preprocess
         if self.image_encoder is None:
             raise NotImplementedError("pass `ip_adapter_image_embeds` or attach an image encoder (encoders.HipDinov2)")
-        px = image if torch.is_tensor(image) else dinov2_preprocess(image)
+        pre = clip_preprocess if isinstance(self.image_encoder, HipCLIPVision) else dinov2_preprocess
+        px = image if torch.is_tensor(image) else pre(image)
         return self.image_encoder.encode_image_pair(px)
 
     def prepare_ip_adapter_image_embeds(self, ip_adapter_image, do_cfg):
@@ -376,9 +434,19 @@ class InstantIRPipeline:
         bit-reproducible parity runs: `init_noise` (the randn of init_latents) and
         `step_noises` (list of per-step DDPM noises) replace draws from `generator` when given.
         `image` must be the LQ *latent* (B,4,h,w) here unless a VAE is attached (`image.shape[1] == 4` branch of :1369-1382)."""
+        # :1531-1535 merges the caller's dict over {"temb": emb} and hands it to both UNet passes.  What a key can do there:
+        # "scale" is popped by diffusers' UNet forward and scales every LoRA layer for that pass (it also sets the text-encoder
+        # LoRA scale, :1324-1326 -- no text-encoder LoRA exists on this path); "temb" / "external_kv" are the processors' own
+        # arguments (module/ip_adapter/attention_processor.py:1093-1100): the loop owns `temb`, and no caller passes `external_kv`;
+        # any other key is a TypeError inside the reference's processors.  "scale" is honoured by building the previewer's
+        # merged copy with scale * alpha / r; the rest is refused with the reason.
+        lora_mult = 1.0
         if cross_attention_kwargs:
-            raise NotImplementedError("cross_attention_kwargs are not forwarded: the attention processors are fixed kernels "
-                                      "(the LoRA scale is folded into the previewer weight copy at prepare_previewers)")
+            extra = set(cross_attention_kwargs) - {"scale"}
+            if extra:
+                raise ValueError(f"cross_attention_kwargs keys {sorted(extra)} are not accepted: the TA-IP attention processors take "
+                                 "`temb` (set by the loop) and nothing a caller may override; only 'scale' (LoRA scale) is honoured")
+            lora_mult = float(cross_attention_kwargs["scale"])
         if multistep_restore:
             raise NotImplementedError("multistep_restore passes kwargs the shipped DDPM scheduler does not accept "
                                       "(SURVEY.md Appendix C Q5)")
@@ -393,7 +461,7 @@ class InstantIRPipeline:
         self._guidance_scale = guidance_scale
         cfg, dev = self.cfg, self.device
         do_cfg = self.do_classifier_free_guidance
-        self._build()
+        self._build(lora_mult)
 
         if prompt_embeds is None:                                                   # :1325-1348
             prompt_embeds, ne, pooled_prompt_embeds, npool = self.encode_prompt(

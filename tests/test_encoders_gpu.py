@@ -146,3 +146,41 @@ def test_pipeline_with_encoders_attached():
     b = p2(prompt_embeds=pe, pooled_prompt_embeds=pooled, ip_adapter_image_embeds=feats,
            previewer_scheduler=LCMSingleStepScheduler.from_config(p2.scheduler.config), **common).images
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_clip_vision_matches_transformers(act):
+    """`use_clip_encoder` branch (module/ip_adapter/utils.py:106-118): `hidden_states[-2]` of the image and of a zero image
+    (pipelines/sdxl_instantir.py:644-654, what a Resampler projector is fed) and `image_embeds` (:656-659), against
+    transformers' CLIPVisionModelWithProjection with the same random weights (transformers 5.x here, not the pinned 4.36.2)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from instantir_amd.encoders import HipCLIPVision
+    torch.manual_seed(7)
+    c = CLIPVisionConfig(hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2, image_size=56,
+                         patch_size=14, projection_dim=96, hidden_act=act)
+    m = CLIPVisionModelWithProjection(c).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.ndim == 1 and "norm" in n:
+                p.add_(0.05 * torch.randn_like(p))
+            elif "position_embedding" in n or "class_embedding" in n:
+                p.copy_(0.3 * torch.randn_like(p))
+    sd = {k: v.half().float() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    x = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        out = m(pixel_values=x, output_hidden_states=True)
+        outz = m(pixel_values=torch.zeros_like(x), output_hidden_states=True)
+    enc = HipCLIPVision(sd, "cuda:0", hidden_act=act)
+    h, emb = enc(x, with_embeds=True)
+    assert h.shape == (2, 17, 128) and emb.shape == (2, 96)
+    assert psnr(h.float().cpu(), out.hidden_states[-2]) > 45
+    assert psnr(emb.float().cpu(), out.image_embeds) > 40
+    f, z = enc.encode_image_pair(x)
+    assert psnr(f.float().cpu(), out.hidden_states[-2]) > 45 and psnr(z.float().cpu(), outz.hidden_states[-2]) > 45
+    with pytest.raises(ValueError):          # fixed position table
+        enc(torch.zeros(1, 3, 70, 70))
+    with pytest.raises(ValueError):          # head_dim 80 towers (ViT-H/14) are refused with the reason
+        HipCLIPVision(sd, "cuda:0", num_heads=1)

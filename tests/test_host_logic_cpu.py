@@ -157,8 +157,8 @@ def test_pipeline_input_checks_raise_like_the_reference():
             {"conv_in.lora_A.weight": torch.zeros(1)})
     with pytest.raises(NotImplementedError):
         pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=torch.zeros(1, 4, 8, 8), multistep_restore=True)
-    with pytest.raises(NotImplementedError):            # never silently ignored
-        pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=torch.zeros(1, 4, 8, 8), cross_attention_kwargs={"scale": 0.5})
+    with pytest.raises(ValueError):                     # keys the TA-IP processors do not take are refused, never silently ignored
+        pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=torch.zeros(1, 4, 8, 8), cross_attention_kwargs={"gligen": {}})
 
 
 def test_aggregator_state_dict_is_strict():

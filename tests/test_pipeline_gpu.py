@@ -316,3 +316,43 @@ def test_single_step_previewer_restoration_fp8(env):
     p_oracle, p_16 = psnr(got8, want), psnr(got8, got16)
     assert torch.isfinite(got8).all() and p_oracle >= 20 and p_16 >= 20, (p_oracle, p_16)
     assert not torch.equal(got8, got16)                      # the fp8 weight set is really in use
+
+
+def test_adapter_switching_and_lora_scale(env):
+    """Two LoRA adapters as in gradio_demo/app.py:67-69,114-120: `prepare_previewers(...)` registers `previewer`,
+    `prepare_previewers(..., use_lcm=True)` registers `lcm` and -- like diffusers' `add_adapter` -- leaves the newest active;
+    `pipe.unet.set_adapter` picks the one the previewer pass uses.  `cross_attention_kwargs={"scale": s}` (:1531-1535, popped by
+    diffusers' UNet forward into `scale_lora_layers`) scales the active LoRA for that pass.  Each variant against the oracle
+    loop run with that LoRA / scaling.  (peft / diffusers are absent here: their adapter bookkeeping is restated, unpinned.)"""
+    from instantir_amd import weights as W
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    lcm_lora = W.synth_state_dict(W.lora_specs(cfg, W.LCM_LORA_MODULES), 14)
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    assert pipe.unet.active_adapters() == ["previewer"]
+    assert pipe.prepare_previewers(lcm_lora, use_lcm=True, lora_alpha=8) == 8
+    assert pipe.unet.active_adapters() == ["lcm"]
+    kw = dict(num_inference_steps=2, guidance_scale=5.0)
+
+    def oracle(lo, scaling):
+        from oracle import pipeline as OP
+        L = {k: v.float() for k, v in lo.items()}
+        L["scaling"] = scaling
+        return OP.denoise({k: v.float() for k, v in sd.items()}, {k: v.float() for k, v in sda.items()}, L, cfg, inp["lq"],
+                          inp["pe"], inp["pooled"], inp["img"], negative_prompt_embeds=inp["npe"], negative_pooled=inp["npooled"],
+                          init_noise=inp["init_noise"], sampler="ddim", **kw)
+
+    got_lcm = _call(pipe, inp, **kw)
+    assert psnr(got_lcm, oracle(lcm_lora, 8.0 / cfg.lora_rank)) >= BAR
+    pipe.unet.set_adapter("previewer")
+    got_prev = _call(pipe, inp, **kw)
+    want_prev = oracle(lora, 16.0 / cfg.lora_rank)
+    assert psnr(got_prev, want_prev) >= BAR
+    assert psnr(got_lcm, want_prev) < BAR - 10                   # the two adapters really differ
+    got_half = _call(pipe, inp, cross_attention_kwargs={"scale": 0.5}, **kw)
+    assert psnr(got_half, oracle(lora, 0.5 * 16.0 / cfg.lora_rank)) >= BAR
+    assert psnr(_call(pipe, inp, **kw), want_prev) >= BAR         # the unscaled copy is still the default afterwards
+    with pytest.raises(ValueError):
+        _call(pipe, inp, cross_attention_kwargs={"external_kv": None}, **kw)
+    with pytest.raises(ValueError):
+        pipe.unet.set_adapter("nope")

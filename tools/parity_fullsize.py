@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--size", type=int, default=1024); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--guidance", type=float, default=7.0)
+ap.add_argument("--size", type=int, default=1024); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--guidance", type=float, default=7.0); ap.add_argument("--control_guidance_end", type=float, default=1.0)
 a = ap.parse_args()
 from instantir_amd import lib, weights as W
 from instantir_amd.config import UNetConfig
@@ -41,7 +41,7 @@ noise = torch.randn(B, 4, H, H, generator=g); alpha = 8
 pipe = InstantIRPipeline(cfg, sd, scheduler=DDIMScheduler(), device=dev)
 pipe.aggregator.load_state_dict(sda); pipe.prepare_previewers(lora, lora_alpha=alpha)
 got = pipe(image=lq, prompt_embeds=pe, pooled_prompt_embeds=pooled, negative_prompt_embeds=npe, negative_pooled_prompt_embeds=npooled,
-           ip_adapter_image_embeds=[feats], output_type="latent", num_inference_steps=a.steps, guidance_scale=a.guidance, init_noise=noise,
+           ip_adapter_image_embeds=[feats], output_type="latent", num_inference_steps=a.steps, guidance_scale=a.guidance, init_noise=noise, control_guidance_end=a.control_guidance_end,
            previewer_scheduler=LCMSingleStepScheduler.from_config(pipe.scheduler.config)).images.float().cpu()
 print(f"HIP path done ({time.time() - t00:.0f} s), finite={bool(torch.isfinite(got).all())}; CPU oracle on {cores()} cores ...", flush=True)
 torch.set_num_threads(cores())
@@ -50,8 +50,8 @@ L["scaling"] = alpha / cfg.lora_rank
 del sd, sda, lora, pipe; torch.cuda.empty_cache()
 with torch.no_grad():
     want = OP.denoise(P, PA, L, cfg, lq, pe, pooled, feats, negative_prompt_embeds=npe, negative_pooled=npooled, init_noise=noise,
-                      num_inference_steps=a.steps, guidance_scale=a.guidance, sampler="ddim")
+                      num_inference_steps=a.steps, guidance_scale=a.guidance, sampler="ddim", control_guidance_end=a.control_guidance_end)
 stop.set()
 mse = ((got - want) ** 2).mean().item()
 p = 10 * math.log10(want.abs().max().item() ** 2 / max(mse, 1e-30))
-print(f"RESULT size={a.size} cfg={a.guidance} steps={a.steps}: latent PSNR vs CPU fp32 oracle {p:.1f} dB (max |want| {want.abs().max().item():.3f}, rmse {mse ** 0.5:.2e}); total {time.time() - t00:.0f} s", flush=True)
+print(f"RESULT size={a.size} cfg={a.guidance} steps={a.steps} control_guidance_end={a.control_guidance_end}: latent PSNR vs CPU fp32 oracle {p:.1f} dB (max |want| {want.abs().max().item():.3f}, rmse {mse ** 0.5:.2e}); total {time.time() - t00:.0f} s", flush=True)
