@@ -82,12 +82,20 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // converted to fp8 in registers (v_cvt_scalef32_pk_fp8_f16, scale 1) -- 4 conversions per fragment, reused by all NI column
 // tiles -- so the MFMA is v_mfma_f32_16x16x32_fp8_fp8.  Staged bytes per K tile drop from (BM + BN) * 128 to
 // BM * 128 + BN * 64: the weight panel, which dominates the level-2 projections' fill, halves.
-template <typename E, int BM, int BN, int ST, bool CONV, int WAVES_M = 2, bool W8 = false>
-__global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_kernel(const Geo g) {
+// LW (loader waves): the workgroup carries NW extra waves that do nothing but issue the LDS-DMA instructions of the K
+// loop (and wait for them); the NW compute waves issue only fragment reads and MFMAs.  With one workgroup per CU (the
+// level-2 projections: 256 tiles of 64x160) a compute wave otherwise sits ~60 cycles in the issue of every 1-KiB LDS-DMA piece,
+// 7 pieces per K tile, with its SIMD's matrix pipe idle behind it (MI355X_MICROARCH.md, LDS-DMA issue cost) -- the "serial
+// round trip" of DESIGN.md section 5.6.  Both kinds of wave meet at the one barrier per K tile; the protocol (tile kt+1 landed
+// and tile kt's buffer drained at the barrier of iteration kt) is unchanged.  All 2*NW waves share the epilogue write-out.
+template <typename E, int BM, int BN, int ST, bool CONV, int WAVES_M = 2, bool W8 = false, bool LW = false>
+__global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1)) void gemm_kernel(const Geo g) {
     static_assert(!(W8 && CONV), "the fp8-weight build covers the linear layers only");
+    static_assert(!(LW && W8), "loader waves: fp16 / bf16 operands only");
     using E4 = typename ET<E>::x4;
     using E8 = typename ET<E>::x8;     // (pointers stay f16-typed: both element types are 2 bytes; only conversions differ)
-    constexpr int NW = WAVES_M * 2, NT = 64 * NW;   // waves laid out WAVES_M x 2 over the tile
+    constexpr int NW = WAVES_M * 2;                 // compute waves, laid out WAVES_M x 2 over the tile (= staging waves)
+    constexpr int NT = 64 * NW * (LW ? 2 : 1);      // threads of the workgroup
     constexpr int WM = BM / WAVES_M, WN = BN / 2;   // wave tile
     constexpr int MI = WM / 16, NI = WN / 16;    // 16x16 MFMA tiles per wave
     constexpr int B_GROUPS = W8 ? BN / 16 : BN / 8;                   // LDS-DMA instructions that cover the weight tile
@@ -101,7 +109,9 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW && wave_all >= NW;                       // wave-uniform role
+    const int wave = loader ? wave_all - NW : wave_all;             // index among the waves of its role
     const int wm = wave >> 1, wn = wave & 1;
 
     // XCD-aware tile order.  Workgroups b, b+8, b+16, ... share an XCD (= one private L2).  The tile grid is
@@ -248,10 +258,12 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     //  reading before it arrived there)
     const int nk_all = g.K / BK;
     const int kt0 = kz ? nk_all / 2 : 0, nk = g.splitk == 2 ? (kz ? nk_all : nk_all / 2) : nk_all;   // this workgroup's K tiles [kt0, nk)
-    if (CONV) conv_seek(kt0);
+    if (!LW || loader) {
+        if (CONV) conv_seek(kt0);
 #pragma unroll
-    for (int s = 0; s < ST - 1; ++s)
-        if (kt0 + s < nk) stage(kt0 + s, s);
+        for (int s = 0; s < ST - 1; ++s)
+            if (kt0 + s < nk) stage(kt0 + s, s);
+    }
 
     // Software-pipelined across the barrier: the fragments of K-step 0 of tile kt+1 are fetched from LDS while the MFMAs of
     // K-step 1 of tile kt run, and the barrier that admits tile kt+1 sits between the two MFMA groups of tile kt -- so no
@@ -294,32 +306,65 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
         }
     };
     auto admit = [&](int tiles_after) {     // wait until only `tiles_after` later tiles are still in flight, all LDS reads done, barrier
-        if (ST >= 4 && tiles_after >= 2) wait_vm_lgkm_and_barrier<(ST >= 4 ? 2 * LOADS : 0)>();
+        if (ST >= 5 && tiles_after >= 3) wait_vm_lgkm_and_barrier<(ST >= 5 ? 3 * LOADS : 0)>();
+        else if (ST >= 4 && tiles_after >= 2) wait_vm_lgkm_and_barrier<(ST >= 4 ? 2 * LOADS : 0)>();
         else if (ST >= 3 && tiles_after >= 1) wait_vm_lgkm_and_barrier<(ST >= 3 ? LOADS : 0)>();
         else wait_vm_lgkm_and_barrier<0>();
     };
     E8 a0[MI], a1[MI];
     BF b0[NI], b1[NI];
-    {
-        const int rem = nk - 1 - kt0;
-        admit(rem < ST - 2 ? rem : ST - 2);
-        if (kt0 + ST - 1 < nk) stage(kt0 + ST - 1, ST - 1);
-        frags(0, 0, a0, b0);
-    }
-    int cur = 0;
-    for (int kt = kt0; kt + 1 < nk; ++kt) {                 // (last tile peeled: no conditional definition of the loop-carried
-        frags(cur, 1, a1, b1);                              //  fragment registers, which cost 80 v_mov per iteration)
+    if constexpr (!LW) {
+        {
+            const int rem = nk - 1 - kt0;
+            admit(rem < ST - 2 ? rem : ST - 2);
+            if (kt0 + ST - 1 < nk) stage(kt0 + ST - 1, ST - 1);
+            frags(0, 0, a0, b0);
+        }
+        int cur = 0;
+        for (int kt = kt0; kt + 1 < nk; ++kt) {                 // (last tile peeled: no conditional definition of the loop-carried
+            frags(cur, 1, a1, b1);                              //  fragment registers, which cost 80 v_mov per iteration)
+            mma(a0, b0);
+            const int rem = nk - 2 - kt;                        // tiles that exist after kt+1
+            admit(rem < ST - 2 ? rem : ST - 2);
+            if (kt + ST < nk) stage(kt + ST, cur);              // tile kt's buffer is free: every wave finished reading it
+            cur = cur + 1 == ST ? 0 : cur + 1;
+            frags(cur, 0, a0, b0);
+            mma(a1, b1);
+        }
+        frags(cur, 1, a1, b1);
         mma(a0, b0);
-        const int rem = nk - 2 - kt;                        // tiles that exist after kt+1
-        admit(rem < ST - 2 ? rem : ST - 2);
-        if (kt + ST < nk) stage(kt + ST, cur);              // tile kt's buffer is free: every wave finished reading it
-        cur = cur + 1 == ST ? 0 : cur + 1;
-        frags(cur, 0, a0, b0);
+        mma(a1, b1);
+    } else if (loader) {
+        // loader waves: same barriers, same counted waits, no LDS reads and no MFMAs
+        {
+            const int rem = nk - 1 - kt0;
+            admit(rem < ST - 2 ? rem : ST - 2);
+            if (kt0 + ST - 1 < nk) stage(kt0 + ST - 1, ST - 1);
+        }
+        int cur = 0;
+        for (int kt = kt0; kt + 1 < nk; ++kt) {
+            const int rem = nk - 2 - kt;
+            admit(rem < ST - 2 ? rem : ST - 2);
+            if (kt + ST < nk) stage(kt + ST, cur);
+            cur = cur + 1 == ST ? 0 : cur + 1;
+        }
+    } else {
+        // compute waves: they issue no vector-memory operation in the loop, so the vmcnt part of `admit` never waits
+        admit(0);
+        frags(0, 0, a0, b0);
+        int cur = 0;
+        for (int kt = kt0; kt + 1 < nk; ++kt) {
+            frags(cur, 1, a1, b1);
+            mma(a0, b0);
+            admit(0);
+            cur = cur + 1 == ST ? 0 : cur + 1;
+            frags(cur, 0, a0, b0);
+            mma(a1, b1);
+        }
+        frags(cur, 1, a1, b1);
+        mma(a0, b0);
         mma(a1, b1);
     }
-    frags(cur, 1, a1, b1);
-    mma(a0, b0);
-    mma(a1, b1);
 
     // ---- epilogue, phase 1: registers -> LDS.  A lane holds row m = ..+frow and 4 consecutive columns n = ..+4*fq+{0..3};
     // stored straight to memory that is 16 rows x 32 B per instruction (16 B for the paired epilogues), which made the
@@ -333,7 +378,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     // (a + b = b + a in fp32, so the result does not depend on which one that is).  Hand-off: all stores of the slab
     // drained by every wave -> workgroup barrier -> one agent-scope release -> relaxed agent-scope ticket; the reducer
     // does one agent-scope acquire, then plain loads (cdna_hip_programming.md, in-launch split-K reduction recipe).
-    if (g.splitk == 2) {
+    if (!LW && g.splitk == 2) {
         const int tile_id = tn * g.tiles_m + tm;
         float* mine = g.sk_slabs + ((long)tile_id * 2 + kz) * (BM * BN);
 #pragma unroll
@@ -365,6 +410,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     }
     if (g.c_f32) {      // fp32 output straight from the accumulators (a lane holds 4 consecutive columns of one row)
         float* c32 = (float*)g.C;
+        if (loader) return;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wm * WM + i * 16 + frow;
@@ -379,6 +425,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     const bool paired = g.epi != IIR_EPI_PLAIN;
     const int cs = (paired ? BN : 2 * BN) + 32;                          // tile row stride in bytes: odd multiple of 32 mod 256
     char* ct = smem;
+    if (!loader) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int lr = wm * WM + i * 16 + frow;            // row inside the tile
@@ -416,18 +463,30 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
                 if (g.bias && n < g.N) { E4 ba = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) a[t] += (float)ba[t]; }
                 float b[4];
                 for (int t = 0; t < 4; ++t) b[t] = __shfl_xor(a[t], 32, 64);     // all lanes take part in the exchange
+                if (g.epi == IIR_EPI_GEGLU) {
+                    // value * gelu(gate): the erf evaluation (14 VALU + v_rcp + v_exp per element) is the cost of this epilogue
+                    // -- kbench 2048x10240x1280: 865 TFLOP/s plain, 735 with value lanes alone doing all four columns -- so
+                    // both lanes of a pair work: the value lane finishes columns 0,1 of the quad, its gate lane columns 2,3.
+                    if (n >= g.N) continue;
+                    const bool gate = fq >= 2;
+                    const int lco = (wn * WN + j * 16) / 2 + (fq & 1) * 4 + (gate ? 2 : 0);
+                    const float v0 = gate ? b[2] : a[0], v1 = gate ? b[3] : a[1], g0 = gate ? a[2] : b[0], g1 = gate ? a[3] : b[1];
+                    typedef E E2 __attribute__((ext_vector_type(2)));
+                    E2 o2 = {(E)(v0 * gelu_erf_f(g0)), (E)(v1 * gelu_erf_f(g1))};
+                    *(E2*)(ct + lr * cs + lco * 2) = o2;
+                    continue;
+                }
                 if (fq >= 2 || n >= g.N) continue;
                 const int lco = (wn * WN + j * 16) / 2 + fq * 4;        // output column inside the tile
                 E4 o;
-                if (g.epi == IIR_EPI_GEGLU) {
-                    for (int t = 0; t < 4; ++t) o[t] = (E)(a[t] * gelu_erf_f(b[t]));
-                } else {   // IIR_EPI_SFT: h * (gamma + 1) + beta, h from `res`
+                {   // IIR_EPI_SFT: h * (gamma + 1) + beta, h from `res`
                     E4 h = *(const E4*)(g.res + mr * g.ldr + n0 / 2 + lco);
                     for (int t = 0; t < 4; ++t) o[t] = (E)((float)h[t] * (a[t] + 1.0f) + b[t]);
                 }
                 *(E4*)(ct + lr * cs + lco * 2) = o;
             }
         }
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile complete
 
@@ -437,7 +496,7 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     auto touch_next_weights = [&]() {
         const int per = (g.pf_lines + (int)gridDim.x - 1) / (int)gridDim.x;
         const long l0 = (long)blockIdx.x * per, last = g.pf_lines - 1;
-        char* scratch = smem + RING_BYTES + wave * 256;
+        char* scratch = smem + RING_BYTES + wave_all * 256;
 #pragma unroll
         for (int i = 0; i < PF_TOUCHES; ++i) {
             long l = l0 + min(tid + i * NT, per - 1);
@@ -535,12 +594,12 @@ __global__ __launch_bounds__(128 * WAVES_M, (WAVES_M == 2 ? 2 : 1)) void gemm_ke
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA touches must land before the LDS is released
 }
 
-template <typename E, int BM, int BN, int ST, int WAVES_M = 2, bool W8 = false>
+template <typename E, int BM, int BN, int ST, int WAVES_M = 2, bool W8 = false, bool LW = false>
 int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 1024;   // ring (reused as the output tile) + prefetch scratch
+    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + (LW ? 2048 : 1024);   // ring (reused as the output tile) + prefetch scratch (256 B per wave)
     // pick the XCD partition (xm x 8/xm rectangles of the tile grid) with the least bytes each 4 MiB L2 pulls over the
     // fabric.  Inside a rectangle tiles walk M fastest, ~64 workgroups are resident per XCD, so its rm x BM rows of A are
     // re-used by successive groups of N-tile columns: if they fit the L2 they are read once, otherwise once per group.
@@ -559,11 +618,17 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
         cost += ((double)rm * rn * 8 - (double)g.tiles_m * g.tiles_n) * 8. * BK * (BM + BN);     // padding workgroups of ragged rectangles
         if (best < 0. || cost < best) { best = cost; g.xm = xm; g.rm = rm; g.rn = rn; }
     }
-    const dim3 grid(8 * g.rm * g.rn * (g.splitk == 2 ? 2 : 1)), block(128 * WAVES_M);
+    const dim3 grid(8 * g.rm * g.rn * (g.splitk == 2 ? 2 : 1)), block(128 * WAVES_M * (LW ? 2 : 1));
     if constexpr (W8) {
         static bool attr_8 = false;
         if (!attr_8) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_8 = true; }
         iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, grid, block, lds, stream, g);
+        return iir_launch_status();
+    } else if constexpr (LW) {
+        if (conv || g.splitk == 2) return IIR_EINVAL;
+        static bool attr_l = false;
+        if (!attr_l) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_l = true; }
+        iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, grid, block, lds, stream, g);
         return iir_launch_status();
     } else
     if (conv) {
@@ -592,6 +657,12 @@ int launch(const Geo& g, bool conv, hipStream_t stream) {
         else return IIR_EINVAL;
     }
     return launch_t<f16, BM, BN, ST, WAVES_M>(g, conv, stream);
+}
+
+template <int BM, int BN, int ST>
+int lw_launch(const Geo& g, bool conv, hipStream_t stream) {
+    if (conv || g.wscale || g.dtype != IIR_DT_F16 || g.splitk == 2) return IIR_EINVAL;
+    return launch_t<f16, BM, BN, ST, 2, false, true>(g, false, stream);
 }
 
 struct TileShape { int bm, bn; };
@@ -654,7 +725,13 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         // ring depth: with at most one workgroup per CU nothing else hides the tile latency, and a long K loop
         // amortises the deeper prologue -> 3 stages for the 64x160 tile (measured +17..40 % on K >= 2560, M*N = 2048x1280)
         const long blocks = (long)((g.M + kTiles[tile].bm - 1) / kTiles[tile].bm) * ((g.N + kTiles[tile].bn - 1) / kTiles[tile].bn);
-        const int stages = (tile == 5 && blocks <= 256 && g.K >= one_per_cu_min_k() && g.dtype == IIR_DT_F16) ? one_per_cu_stages() : IIR_DEFAULT_STAGES;
+        const bool one_per_cu = tile == 5 && blocks <= 256 && g.K >= one_per_cu_min_k() && g.dtype == IIR_DT_F16;
+        const int stages = one_per_cu ? one_per_cu_stages() : IIR_DEFAULT_STAGES;
+        // one workgroup per CU and a plain GEMM: the loader-wave build (kbench, warm: 2048x1280x1280 456 -> 535 TFLOP/s,
+        // K = 5120 645 -> 707; the per-tile slope stays at the ~70 GB/s per-CU L2 -> LDS fill rate, the fixed part drops)
+        static const bool lw_on = !(getenv("IIR_T5_LW") && atoi(getenv("IIR_T5_LW")) == 0);
+        if (one_per_cu && lw_on && !conv && !g.wscale && g.splitk != 2 && stages >= 3 && stages <= 5) tile = stages == 3 ? 55 : stages == 4 ? 65 : 85;
+        else
         tile += 10 * stages;
     }
     switch (tile) {
@@ -668,12 +745,19 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         case 25: return launch<64, 160, 2>(g, conv, stream);
         case 35: return launch<64, 160, 3>(g, conv, stream);
         case 45: return launch<64, 160, 4>(g, conv, stream);
+        case 55: return lw_launch<64, 160, 3>(g, conv, stream);     // 4 compute + 4 loader waves (gemm only, fp16)
+        case 65: return lw_launch<64, 160, 4>(g, conv, stream);
+        case 75: return lw_launch<64, 160, 2>(g, conv, stream);
+        case 85: return lw_launch<64, 160, 5>(g, conv, stream);
         case 34: return launch<128, 160, 3>(g, conv, stream);
         case 42: return launch<128, 64, 4>(g, conv, stream);
         case 26: return launch<256, 128, 2, 4>(g, conv, stream);   // 8 waves, 1 workgroup per CU
         case 36: return launch<256, 128, 3, 4>(g, conv, stream);
         case 29: return launch<32, 160, 2>(g, conv, stream);       // 512 workgroups on a 2048 x 1280 problem: two per CU, 24 KB per K tile each
         case 27: return launch<128, 320, 2, 4>(g, conv, stream);   // 8 waves (4 x 2), 56 KB of operands per K tile: 91 FLOP per staged byte
+        case 90:                                                   // 256x320, 8 waves, 72 KB per K tile: 142 FLOP per staged byte; paired
+            if (g.epi == IIR_EPI_PLAIN) return IIR_EINVAL;         //   epilogues only (the half-width output tile is what fits the ring)
+            return launch<256, 320, 2, 4>(g, conv, stream);
         case 28:                                                   // 8 waves, 64 KB per K tile: 128 FLOP per staged byte; the output tile
             if (g.epi == IIR_EPI_PLAIN && !g.c_f32) return IIR_EINVAL;   //   only fits the ring in its paired (half-width) form
             return launch<256, 256, 2, 4>(g, conv, stream);

@@ -68,7 +68,7 @@ class LaunchProfiler:
 
 PROFILER = None     # set to a LaunchProfiler to time gemm / conv / attention launches
 
-_TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x160", 5: "64x160", 6: "256x128", 7: "128x320", 8: "256x256", 9: "32x160"}
+_TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x160", 5: "64x160", 6: "256x128", 7: "128x320", 8: "256x256", 9: "32x160", 0: "256x320"}   # 0: tile id 90
 
 
 def auto_tile(M, N, paired=False, K=0):

@@ -23,15 +23,18 @@ def _host_cores():
     return n
 
 
-@pytest.mark.parametrize("size,guidance,steps", [(512, 1.0, 4), (512, 7.0, 3), (1024, 7.0, 1)])
-def test_full_sdxl_shapes(size, guidance, steps):
-    """(512, 1.0, 4) is BASELINE configs[0]; (512, 7.0, 3) adds the CFG-doubled batch; (1024, 7.0, 1) is configs[1]'s geometry."""
+@pytest.mark.parametrize("size,guidance,steps,ts", [(512, 1.0, 4, None), (512, 7.0, 3, None), (1024, 7.0, 1, [501])])
+def test_full_sdxl_shapes(size, guidance, steps, ts):
+    """(512, 1.0, 4) is BASELINE configs[0]; (512, 7.0, 3) adds the CFG-doubled batch; (1024, 7.0, 1) is configs[1]'s geometry.
+    The single-step case runs at t = 501 through `timesteps=` with the DDPM scheduler and a given step noise (diffusers' DDIM
+    takes no custom timesteps): a lone DDIM step of a 1-step schedule sits at t = 1, where the network output barely enters the
+    result (it measured 92.7 dB -- a weak check); at t = 501 the epsilon coefficient is ~1.6."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from instantir_amd import lib, weights as W
     from instantir_amd.config import UNetConfig
     from instantir_amd.pipeline import InstantIRPipeline
-    from instantir_amd.schedulers import DDIMScheduler, LCMSingleStepScheduler
+    from instantir_amd.schedulers import DDIMScheduler, DDPMScheduler, LCMSingleStepScheduler
     from oracle import pipeline as OP
     lib.load()
     dev = torch.device("cuda:0")
@@ -49,12 +52,16 @@ def test_full_sdxl_shapes(size, guidance, steps):
     npooled = torch.randn(B, 1280, generator=g).half().float()
     noise = torch.randn(B, 4, H, H, generator=g)
     alpha = 8
-    pipe = InstantIRPipeline(cfg, sd, scheduler=DDIMScheduler(), device=dev)
+    extra, okw = {}, dict(sampler="ddim")
+    if ts is not None:
+        sn = [torch.randn(B, 4, H, H, generator=g) for _ in ts]
+        extra, okw = dict(timesteps=ts, step_noises=sn), dict(sampler="ddpm", timesteps=ts, step_noises=sn)
+    pipe = InstantIRPipeline(cfg, sd, scheduler=DDIMScheduler() if ts is None else DDPMScheduler(), device=dev)
     pipe.aggregator.load_state_dict(sda)
     pipe.prepare_previewers(lora, lora_alpha=alpha)
     got = pipe(image=lq, prompt_embeds=pe, pooled_prompt_embeds=pooled, negative_prompt_embeds=npe,
                negative_pooled_prompt_embeds=npooled, ip_adapter_image_embeds=[feats], output_type="latent",
-               num_inference_steps=steps, guidance_scale=guidance, init_noise=noise,
+               num_inference_steps=steps, guidance_scale=guidance, init_noise=noise, **extra,
                previewer_scheduler=LCMSingleStepScheduler.from_config(pipe.scheduler.config)).images.float().cpu()
     assert torch.isfinite(got).all()
     # CPU oracle on the same (fp16-rounded) weights
@@ -67,10 +74,10 @@ def test_full_sdxl_shapes(size, guidance, steps):
     torch.cuda.empty_cache()
     with torch.no_grad():
         want = OP.denoise(P, PA, L, cfg, lq, pe, pooled, feats, negative_prompt_embeds=npe, negative_pooled=npooled,
-                          init_noise=noise, num_inference_steps=steps, guidance_scale=guidance, sampler="ddim")
+                          init_noise=noise, num_inference_steps=steps, guidance_scale=guidance, **okw)
     mse = ((got - want) ** 2).mean().item()
     p = 10 * math.log10(want.abs().max().item() ** 2 / max(mse, 1e-30))
     print(f"full-shape {size}px cfg={guidance} steps={steps}: latent PSNR vs CPU fp32 oracle {p:.1f} dB")
     from conftest import record_psnr
-    record_psnr(f"fullsize.{size}px.cfg{guidance}.steps{steps}", p)
+    record_psnr(f"fullsize.{size}px.cfg{guidance}.steps{steps}" + ("" if ts is None else f".t{ts[0]}"), p)
     assert p >= 50.0, p

@@ -29,7 +29,7 @@ def _close(got, want, rtol=2e-3, atol=2e-3, what=""):
     assert bad == 0, f"{what}: {bad}/{want.numel()} off, max err {err.max().item():.4g} (ref max {want.abs().max().item():.4g})"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 31, 36])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 31, 36, 55, 65, 75])      # 55 / 65 / 75: 64x160 with loader waves, 3 / 4 / 2 stages
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 132, 64), (2, 320, 320), (1000, 640, 1280)])
 def test_gemm_plain(dev, tile, M, N, K):
     from instantir_amd import ops
@@ -98,7 +98,7 @@ def test_conv_split_k(dev):
         assert ws[:4096].view(torch.int32).abs().max().item() == 0
 
 
-@pytest.mark.parametrize("M,C,tile", [(256, 160, 0), (2048, 640, 0), (200, 128, 0), (512, 128, 2), (96, 64, 3), (1024, 320, 4)])
+@pytest.mark.parametrize("M,C,tile", [(256, 160, 0), (2048, 640, 0), (200, 128, 0), (512, 128, 2), (96, 64, 3), (1024, 320, 4), (1024, 320, 55)])
 def test_gemm_transposed_column_range(dev, M, C, tile):
     """Fused q|k|v projection: columns [0, 2C) row-major, columns [2C, 3C) stored transposed (iir_gemm_desc.Ct) -- whole
     transposed tiles, tiles straddling tr_from and ragged M all give the two plain products."""
@@ -129,8 +129,9 @@ def test_gemm_strided_a_and_scale(dev):
     _close(out, 0.5 * (a.float() @ w.float().T), what="gemm strided")
 
 
-@pytest.mark.parametrize("M,n_out,K", [(256, 128, 64), (130, 48, 128), (64, 2560, 640)])
-def test_gemm_geglu(dev, M, n_out, K):
+@pytest.mark.parametrize("tile", [0, 55, 90])          # 90: 256x320, 8 waves (paired epilogues only)
+@pytest.mark.parametrize("M,n_out,K", [(256, 128, 64), (130, 48, 128), (64, 2560, 640), (520, 400, 256)])
+def test_gemm_geglu(dev, M, n_out, K, tile):
     from instantir_amd import ops
     from instantir_amd.packing import pair_rows
     g = torch.Generator().manual_seed(n_out)
@@ -140,7 +141,7 @@ def test_gemm_geglu(dev, M, n_out, K):
     wp = pair_rows(w[:n_out], w[n_out:]).to(dev)
     bp = pair_rows(b[:n_out], b[n_out:]).to(dev)
     out = torch.empty(M, n_out, dtype=torch.half, device=dev)
-    ops.gemm(a.to(dev), wp, out, bias=bp, epi=ops.EPI_GEGLU)
+    ops.gemm(a.to(dev), wp, out, bias=bp, epi=ops.EPI_GEGLU, tile=tile)
     torch.cuda.synchronize()
     _close(out, want, what="geglu")
 
