@@ -625,10 +625,15 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
         iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, grid, block, lds, stream, g);
         return iir_launch_status();
     } else if constexpr (LW) {
-        if (conv || g.splitk == 2) return IIR_EINVAL;
-        static bool attr_l = false;
-        if (!attr_l) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_l = true; }
-        iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, grid, block, lds, stream, g);
+        if (g.splitk == 2) return IIR_EINVAL;
+        static bool attr_l = false, attr_lc = false;
+        if (conv) {
+            if (!attr_lc) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lc = true; }
+            iir_launch(gemm_kernel<E, BM, BN, ST, true, WAVES_M, false, true>, grid, block, lds, stream, g);
+        } else {
+            if (!attr_l) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_l = true; }
+            iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, grid, block, lds, stream, g);
+        }
         return iir_launch_status();
     } else
     if (conv) {
@@ -661,8 +666,9 @@ int launch(const Geo& g, bool conv, hipStream_t stream) {
 
 template <int BM, int BN, int ST>
 int lw_launch(const Geo& g, bool conv, hipStream_t stream) {
-    if (conv || g.wscale || g.dtype != IIR_DT_F16 || g.splitk == 2) return IIR_EINVAL;
-    return launch_t<f16, BM, BN, ST, 2, false, true>(g, false, stream);
+    if (g.wscale || g.dtype != IIR_DT_F16 || g.splitk == 2) return IIR_EINVAL;
+    if constexpr (ST == 3) return launch_t<f16, BM, BN, ST, 2, false, true>(g, conv, stream);
+    else { if (conv) return IIR_EINVAL; return launch_t<f16, BM, BN, ST, 2, false, true>(g, false, stream); }
 }
 
 struct TileShape { int bm, bn; };
@@ -730,7 +736,8 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         // one workgroup per CU and a plain GEMM: the loader-wave build (kbench, warm: 2048x1280x1280 456 -> 535 TFLOP/s,
         // K = 5120 645 -> 707; the per-tile slope stays at the ~70 GB/s per-CU L2 -> LDS fill rate, the fixed part drops)
         static const bool lw_on = !(getenv("IIR_T5_LW") && atoi(getenv("IIR_T5_LW")) == 0);
-        if (one_per_cu && lw_on && !conv && !g.wscale && g.splitk != 2 && stages >= 3 && stages <= 5) tile = stages == 3 ? 55 : stages == 4 ? 65 : 85;
+        static const bool lw_conv = !(getenv("IIR_T5_LWCONV") && atoi(getenv("IIR_T5_LWCONV")) == 0);
+        if (one_per_cu && lw_on && (!conv || (lw_conv && stages == 3)) && !g.wscale && g.splitk != 2 && stages >= 3 && stages <= 5) tile = stages == 3 ? 55 : stages == 4 ? 65 : 85;
         else
         tile += 10 * stages;
     }

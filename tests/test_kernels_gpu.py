@@ -153,7 +153,8 @@ def _nhwc(x):
 @pytest.mark.parametrize("R,H,W,Cin,Cout,stride,ups", [
     (2, 16, 16, 64, 64, 1, False), (1, 9, 7, 128, 96, 1, False), (2, 16, 16, 64, 128, 2, False),
     (2, 8, 8, 64, 64, 1, True), (1, 32, 16, 320, 320, 1, False)])
-def test_conv3x3(dev, R, H, W, Cin, Cout, stride, ups):
+@pytest.mark.parametrize("tile", [0, 55])          # 55: 64x160 with loader waves (the one-workgroup-per-CU convs)
+def test_conv3x3(dev, R, H, W, Cin, Cout, stride, ups, tile):
     from instantir_amd import ops
     from instantir_amd.packing import conv_weight_nhwc
     g = torch.Generator().manual_seed(H * W + Cin)
@@ -168,7 +169,7 @@ def test_conv3x3(dev, R, H, W, Cin, Cout, stride, ups):
     xd[..., :Cin] = _nhwc(x).to(dev)
     out = torch.empty(R * Ho * Wo, Cout, dtype=torch.half, device=dev)
     ops.conv2d(xd[..., :Cin], conv_weight_nhwc(w).to(dev), out, ksize=3, stride=stride, upsample=ups, bias=b.to(dev),
-               rowbias=temb.to(dev), rows_per_rb=Ho * Wo, res=_nhwc(res).reshape(-1, Cout).to(dev))
+               rowbias=temb.to(dev), rows_per_rb=Ho * Wo, res=_nhwc(res).reshape(-1, Cout).to(dev), tile=tile)
     torch.cuda.synchronize()
     _close(out, want, what="conv3x3")
 
