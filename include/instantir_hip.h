@@ -67,6 +67,13 @@ typedef struct iir_gemm_desc {
     const void* wscale;            /* != NULL: W holds fp8-E4M3 (OCP) BYTES [N][K] and wscale[n] (fp32, 16-byte aligned) is */
                                    /*   the scale of row n: C = epi((A8 . W8^T) * wscale[n] ...), A converted to fp8 in the */
                                    /*   kernel (BASELINE configs[4]: "fp8 MFMA weights" for the LCM single-step path)       */
+    /* LayerNorm without a LayerNorm launch (nn.LayerNorm -> nn.Linear pairs of BasicTransformerBlock, module/min_sdxl.py:541-562):  */
+    void* ln_stats_out;            /* producer side, optional: the launch that WRITES the residual stream also leaves, per row and   */
+                                   /*   per column tile, (mean, M2) of the fp16 values it stored: float2 [iir_gemm_ln_parts()][M]    */
+    const void* ln_stats_in;       /* consumer side, optional: A holds the RAW (un-normalised) rows; W must be W . diag(gamma),      */
+    int32_t ln_parts, ln_part_cols;/*   bias must carry W . beta; the kernel merges the `ln_parts` partials of each row (each over   */
+    float ln_eps;                  /*   `ln_part_cols` columns; parts x cols == K) to (mean, rstd) and forms                         */
+    const void* ln_colsum;         /*   C = epi(rstd * (A . W^T) - rstd * mean * ln_colsum[n] + bias ...), ln_colsum[n] = sum_k W[n][k] (fp32) */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -74,6 +81,8 @@ typedef struct iir_gemm_desc {
  * feed-forward module/min_sdxl.py:502-528; proj_in/out :572,575; time_emb_proj :266; embeddings
  * :226-240; AdaLayerNorm linear attention_processor.py:23; Resampler resampler.py:48-49,66-68,95-97. */
 int iir_gemm_f16(const iir_gemm_desc* d, void* stream);
+/* partials per row a tile = 0, plain-epilogue launch of (M, N, K) writes to `ln_stats_out`; 0 = that launch cannot (ragged tiles) */
+int iir_gemm_ln_parts(int32_t M, int32_t N, int32_t K);
 /* the tile `tile = 0` resolves to for an (M, N, K) problem (paired != 0 for GEGLU / SFT epilogues) */
 int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired);
 /* bytes of split-K workspace an (M, N) problem can use (0: the split form does not apply to it) */

@@ -60,7 +60,21 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     int dtype;                      // IIR_DT_F16 / IIR_DT_BF16: element type of A, W, C, bias, rowbias, res
     int c_f32;                      // C is float (plain epilogue, out_scale only): the VAE's attention scores
     const float* wscale;            // W8 build: W holds fp8-E4M3 bytes [N][K], wscale[n] its per-output-channel scale (fp32)
+    // LayerNorm folded into the GEMMs either side of it ("LayerNorm without a LayerNorm launch"):
+    float* ln_out;                  // producer: per (column tile, row) partial (mean, M2) of the rows it writes, [N/BN][M] float2
+    const float* ln_in;             // consumer: those partials; A holds the RAW rows, W has gamma folded in
+    int ln_parts, ln_part_cols;     //   partial count per row and the columns each one covers
+    float ln_eps;
+    const float* ln_colsum;         //   s[n] = sum_k W[n][k] (fp32): y = rstd * (x . w_n) - rstd * mean * s[n] (+ bias, which carries W . beta)
 };
+
+// Chan's pairwise update of (count, mean, M2) -- the same form norm.hip uses for GroupNorm
+__device__ __forceinline__ void ln_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    const float tot = n + nb, d = mb - mean;
+    mean += d * (nb / tot);
+    m2 += m2b + d * d * (n * nb / tot);
+    n = tot;
+}
 
 constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
 
@@ -106,6 +120,10 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     f16* As = (f16*)smem;                       // [ST][BM][64]
     f16* Bs = As + ST * BM * BK;                // [ST][BN][64]  (W8: [ST][BN][64 bytes])
     constexpr int LOADS = A_INST + B_INST;      // LDS-DMA instructions per wave per stage (every wave issues exactly this many)
+    constexpr int SCRATCH_BYTES = LW ? 2048 : 1024;
+    float2* rowstat = (float2*)(smem + RING_BYTES + SCRATCH_BYTES);          // [BM] (rstd, -rstd * mean) of this tile's rows (ln_in)
+    constexpr int LNP_OFF = (BM * (2 * BN + 32) + 15) / 16 * 16;              // producer partials sit behind the finished output tile
+    constexpr bool LN_OUT_FITS = LNP_OFF + BM * (BN / 8) * 8 <= RING_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -264,6 +282,18 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         for (int s = 0; s < ST - 1; ++s)
             if (kt0 + s < nk) stage(kt0 + s, s);
     }
+    // LayerNorm statistics of this tile's rows: the producer's per-column-tile partials are FETCHED here, behind the first K
+    // tiles' LDS-DMA, and merged only after the K loop (a merge up front, with its load latency and divisions on two of the
+    // four waves, delayed every workgroup's first barrier: +12.8 us on the 2048 x 10240 x 1280 GEGLU projection).
+    constexpr int MAXP = 8;
+    float2 lnp_in[MAXP];
+    const int ln_lt = LW ? tid - 64 * NW : tid;          // LW builds: the loader waves carry them
+    if (g.ln_in && ln_lt >= 0 && ln_lt < BM) {
+        const int m = min(m0 + ln_lt, g.M - 1);
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j)              // unconditional (clamped) loads: one straight-line batch; absent groups are masked at the merge
+            lnp_in[j] = ((const float2*)g.ln_in)[(long)min(j, g.ln_parts - 1) * g.M + m];
+    }
 
     // Software-pipelined across the barrier: the fragments of K-step 0 of tile kt+1 are fetched from LDS while the MFMAs of
     // K-step 1 of tile kt run, and the barrier that admits tile kt+1 sits between the two MFMA groups of tile kt -- so no
@@ -372,6 +402,23 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     // activation / GEGLU / SFT applied) goes through the now idle ring, and phase 2 writes whole rows, 16 B per lane,
     // adding the residual from equally coalesced loads.  (fp16 rounding before the residual add = torch's own order:
     // the Linear / Conv output is an fp16 tensor before `+ residual`.)
+    if (g.ln_in && ln_lt >= 0 && ln_lt < BM) {
+        // equal-count groups: mean = average of the group means, M2 = sum of the group M2 + cols * sum (mean_j - mean)^2
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) sm += j < g.ln_parts ? lnp_in[j].x : 0.f;
+        const float inv_p = 1.0f / (float)g.ln_parts, mean = sm * inv_p;
+        float m2 = 0.f, dev = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const float d = lnp_in[j].x - mean;
+            m2 += j < g.ln_parts ? lnp_in[j].y : 0.f;
+            dev += j < g.ln_parts ? d * d : 0.f;
+        }
+        const float var = (m2 + (float)g.ln_part_cols * dev) * inv_p / (float)g.ln_part_cols;
+        const float rstd = rsqrtf(var + g.ln_eps);
+        rowstat[ln_lt] = make_float2(rstd, -rstd * mean);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading the ring
 
     // ---- split-K: whichever of a tile's two workgroups finishes LAST adds the other's fp32 partial and runs the epilogue
@@ -426,22 +473,33 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     const int cs = (paired ? BN : 2 * BN) + 32;                          // tile row stride in bytes: odd multiple of 32 mod 256
     char* ct = smem;
     if (!loader) {
+    // column-outer, row-inner: what depends on the column only (bias, fp8 scale, LayerNorm column sum) is fetched once per
+    // 16-column group and lane, not once per accumulator tile (with `ln_in` the per-tile form cost the GEGLU projection 26 us)
+    int lrs[MI], ms[MI];
+    float2 rss[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int lr = wm * WM + i * 16 + frow;            // row inside the tile
-        int m = m0 + lr;
-        if (m >= g.M) m = g.M - 1;                         // tail rows: computed from clamped operands, dropped in phase 2
-        const f16* rb = g.rowbias ? g.rowbias + (long)(m / g.rows_per_rb) * g.ldrb : nullptr;
-        if (!paired) {
+        lrs[i] = wm * WM + i * 16 + frow;                  // row inside the tile
+        ms[i] = min(m0 + lrs[i], g.M - 1);                 // tail rows: computed from clamped operands, dropped in phase 2
+        rss[i] = g.ln_in ? rowstat[lrs[i]] : make_float2(1.f, 0.f);
+    }
+    if (!paired) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int lc = wn * WN + j * 16 + fq * 4;
-                const int n = n0 + lc;
-                if (n >= g.N) continue;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (W8) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) v[t] *= ws[t]; }
-                if (g.bias) { E4 b = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
-                if (rb) { E4 b = *(const E4*)(rb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
+        for (int j = 0; j < NI; ++j) {
+            const int lc = wn * WN + j * 16 + fq * 4;
+            const int n = n0 + lc;
+            if (n >= g.N) continue;
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+            if (W8) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) sc[t] = ws[t]; }
+            if (g.ln_in) { const f32x4 cs4 = *(const f32x4*)(g.ln_colsum + n); for (int t = 0; t < 4; ++t) c1[t] = cs4[t]; }
+            if (g.bias) { E4 b = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) c0[t] = (float)b[t]; }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int lr = lrs[i];
+                float v[4];
+                for (int t = 0; t < 4; ++t) v[t] = W8 ? acc[i][j][t] * sc[t] : acc[i][j][t];
+                for (int t = 0; t < 4; ++t) v[t] = fmaf(v[t], rss[i].x, fmaf(rss[i].y, c1[t], c0[t]));     // (1, 0) without ln_in
+                if (g.rowbias) { E4 b = *(const E4*)(g.rowbias + (long)(ms[i] / g.rows_per_rb) * g.ldrb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
                 else if (g.act == IIR_ACT_GELU) for (int t = 0; t < 4; ++t) v[t] = gelu_erf_f(v[t]);
                 else if (g.act == IIR_ACT_QUICKGELU) for (int t = 0; t < 4; ++t) v[t] = v[t] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[t]));
@@ -449,25 +507,32 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
                 for (int t = 0; t < 4; ++t) o[t] = (E)v[t];
                 *(E4*)(ct + lr * cs + lc * 2) = o;
             }
-        } else {
-            // paired columns: in every 16-column group of the (row-permuted) weight the first 8 are the "value" rows and
-            // the next 8 their partners (gate for GEGLU; beta for SFT).  A lane holds 4 consecutive columns, so value
-            // lanes (fq = 0,1) fetch their partner from lane + 32 (fq + 2) with one cross-half exchange per register.
-            long mr = m;
-            if (CONV && g.res_img_rows) { const int hw = g.Ho * g.Wo, img = m / hw; mr = (long)img * g.res_img_rows + (m - img * hw); }
+        }
+    } else {
+        // paired columns: in every 16-column group of the (row-permuted) weight the first 8 are the "value" rows and
+        // the next 8 their partners (gate for GEGLU; beta for SFT).  A lane holds 4 consecutive columns, so value
+        // lanes (fq = 0,1) fetch their partner from lane + 32 (fq + 2) with one cross-half exchange per register.
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = n0 + wn * WN + j * 16 + fq * 4;           // permuted column held by this lane
-                float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (W8 && n < g.N) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) a[t] *= ws[t]; }
-                if (g.bias && n < g.N) { E4 ba = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) a[t] += (float)ba[t]; }
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WN + j * 16 + fq * 4;           // permuted column held by this lane
+            const bool in_n = n < g.N;
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+            if (W8 && in_n) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) sc[t] = ws[t]; }
+            if (g.ln_in && in_n) { const f32x4 cs4 = *(const f32x4*)(g.ln_colsum + n); for (int t = 0; t < 4; ++t) c1[t] = cs4[t]; }
+            if (g.bias && in_n) { E4 ba = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) c0[t] = (float)ba[t]; }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int lr = lrs[i];
+                float a[4];
+                for (int t = 0; t < 4; ++t) a[t] = W8 ? acc[i][j][t] * sc[t] : acc[i][j][t];
+                for (int t = 0; t < 4; ++t) a[t] = fmaf(a[t], rss[i].x, fmaf(rss[i].y, c1[t], c0[t]));
                 float b[4];
                 for (int t = 0; t < 4; ++t) b[t] = __shfl_xor(a[t], 32, 64);     // all lanes take part in the exchange
                 if (g.epi == IIR_EPI_GEGLU) {
                     // value * gelu(gate): the erf evaluation (14 VALU + v_rcp + v_exp per element) is the cost of this epilogue
                     // -- kbench 2048x10240x1280: 865 TFLOP/s plain, 735 with value lanes alone doing all four columns -- so
                     // both lanes of a pair work: the value lane finishes columns 0,1 of the quad, its gate lane columns 2,3.
-                    if (n >= g.N) continue;
+                    if (!in_n) continue;
                     const bool gate = fq >= 2;
                     const int lco = (wn * WN + j * 16) / 2 + (fq & 1) * 4 + (gate ? 2 : 0);
                     const float v0 = gate ? b[2] : a[0], v1 = gate ? b[3] : a[1], g0 = gate ? a[2] : b[0], g1 = gate ? a[3] : b[1];
@@ -476,8 +541,10 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
                     *(E2*)(ct + lr * cs + lco * 2) = o2;
                     continue;
                 }
-                if (fq >= 2 || n >= g.N) continue;
+                if (fq >= 2 || !in_n) continue;
                 const int lco = (wn * WN + j * 16) / 2 + fq * 4;        // output column inside the tile
+                long mr = ms[i];
+                if (CONV && g.res_img_rows) { const int hw = g.Ho * g.Wo, img = ms[i] / hw; mr = (long)img * g.res_img_rows + (ms[i] - img * hw); }
                 E4 o;
                 {   // IIR_EPI_SFT: h * (gamma + 1) + beta, h from `res`
                     E4 h = *(const E4*)(g.res + mr * g.ldr + n0 / 2 + lco);
@@ -564,6 +631,39 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
                 if (TOTAL % NT != 0 && c >= TOTAL) break;
                 *(E8*)(g.C + (long)(m0 + r) * g.ldc + no_tile + cc * 8) = o[k];
             }
+            if constexpr (LN_OUT_FITS) {
+                if (g.ln_out) {
+                    // the rows just written feed a LayerNorm: leave (mean, M2) of this tile's BN columns of every row, taken
+                    // from the ROUNDED values (what the next GEMM reads).  Per 8-column chunk in registers, then one thread per
+                    // row merges the row's CPR chunks in a fixed order (the merge weights are compile-time constants).
+                    float2* lnp = (float2*)(smem + LNP_OFF);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int c = tid + k * NT;
+                        if (TOTAL % NT != 0 && c >= TOTAL) break;
+                        float f[8], sum = 0.f, q = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) { f[t] = (float)o[k][t]; sum += f[t]; }
+                        const float mu = sum * 0.125f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) { const float d = f[t] - mu; q = fmaf(d, d, q); }
+                        lnp[c] = make_float2(mu, q);                                 // c = r * CPR + cc
+                    }
+                    __syncthreads();
+                    if (tid < BM) {
+                        float2 acc2 = lnp[tid * CPR];
+                        float mean = acc2.x, m2 = acc2.y;
+#pragma unroll
+                        for (int j = 1; j < CPR; ++j) {
+                            const float2 pj = lnp[tid * CPR + j];
+                            const float d = pj.x - mean;
+                            mean += d * (1.0f / (float)(j + 1));
+                            m2 += pj.y + d * d * (8.0f * (float)j / (float)(j + 1));
+                        }
+                        ((float2*)g.ln_out)[(long)tn * g.M + m0 + tid] = make_float2(mean, m2);
+                    }
+                }
+            }
         } else {
             // ragged edge / unaligned rows / per-image row remap: element-wise, speed irrelevant
             touch_next_weights();
@@ -599,7 +699,12 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + (LW ? 2048 : 1024);   // ring (reused as the output tile) + prefetch scratch (256 B per wave)
+    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + (LW ? 2048 : 1024) + BM * 8;   // ring (reused as the output tile) + prefetch scratch (256 B per wave) + LayerNorm row statistics
+    if (g.ln_out) {         // producer of LayerNorm partials: whole tiles, 16-byte rows, plain epilogue (see the kernel's fast write-out path)
+        constexpr bool fits = (BM * (2 * BN + 32) + 15) / 16 * 16 + BM * (BN / 8) * 8 <= ST * (BM * 128 + (W8 ? BN * 64 : BN * 128));
+        if (!fits || conv || g.epi != IIR_EPI_PLAIN || g.c_f32 || g.Ct || g.splitk == 2 || g.M % BM || g.N % BN || !g.c_vec || (g.res && !g.r_vec))
+            return IIR_EINVAL;
+    }
     // pick the XCD partition (xm x 8/xm rectangles of the tile grid) with the least bytes each 4 MiB L2 pulls over the
     // fabric.  Inside a rectangle tiles walk M fastest, ~64 workgroups are resident per XCD, so its rm x BM rows of A are
     // re-used by successive groups of N-tile columns: if they fit the L2 they are read once, otherwise once per group.
@@ -720,7 +825,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // of K on exactly those (51.8 vs 44.8 us warm at K = 5120, equal at K = 11520, 73.9 vs 73.0 ms per step): the agent-scope
     // release per workgroup and the fp32 slab round trip cost more than the smaller operand fill saves.  The engine does
     // not pass a workspace unless IIR_SPLITK=1.
-    if (tile == 0 && g.sk_slabs && g.dtype == IIR_DT_F16 && uses_splitk(g.M, g.N, g.K, g.sk_bytes)) {
+    if (tile == 0 && g.sk_slabs && !g.ln_out && !g.ln_in && g.dtype == IIR_DT_F16 && uses_splitk(g.M, g.N, g.K, g.sk_bytes)) {
         Geo g2 = g;
         g2.splitk = 2;
         return launch<128, 160, 3>(g2, conv, stream);
@@ -788,6 +893,15 @@ extern "C" int iir_gemm_uses_splitk(int32_t M, int32_t N, int32_t K, int64_t ws_
 
 extern "C" int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired) { return pick_tile(M, N, paired != 0, K); }
 
+// Partials per row a tile = 0, plain-epilogue launch of (M, N, K) leaves in `ln_stats_out` (= N / BN of the tile it resolves to), or 0
+// when that launch cannot produce them (ragged tiles).  The buffer is [parts][M] float2.
+extern "C" int iir_gemm_ln_parts(int32_t M, int32_t N, int32_t K) {
+    const int t = pick_tile(M, N, false, K);
+    const int bm = kTiles[t].bm, bn = kTiles[t].bn;
+    if (t < 1 || t > 5 || M % bm || N % bn || N / bn > 8) return 0;      // (the consumer holds at most 8 partials per row in registers)
+    return N / bn;
+}
+
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     (void)hipGetLastError();
     if (!d || !d->A || !d->W || !d->C) return IIR_EINVAL;
@@ -822,6 +936,16 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     }
     if (d->splitk_ws && d->splitk_ws_bytes > SK_CNT_BYTES) {
         g.sk_cnt = (int*)d->splitk_ws; g.sk_slabs = (float*)((char*)d->splitk_ws + SK_CNT_BYTES); g.sk_bytes = d->splitk_ws_bytes;
+    }
+    if (d->ln_stats_out) {
+        if ((uintptr_t)d->ln_stats_out % 8 || d->c_f32 || d->Ct || d->epi != IIR_EPI_PLAIN) return IIR_EINVAL;
+        g.ln_out = (float*)d->ln_stats_out;
+    }
+    if (d->ln_stats_in) {
+        if (!d->ln_colsum || d->ln_parts <= 0 || d->ln_parts > 8 || d->ln_part_cols <= 0 || (long)d->ln_parts * d->ln_part_cols != d->K || d->c_f32 ||
+            (uintptr_t)d->ln_stats_in % 8 || (uintptr_t)d->ln_colsum % 16 || !(d->ln_eps > 0.f)) return IIR_EINVAL;
+        g.ln_in = (const float*)d->ln_stats_in; g.ln_colsum = (const float*)d->ln_colsum;
+        g.ln_parts = d->ln_parts; g.ln_part_cols = d->ln_part_cols; g.ln_eps = d->ln_eps;
     }
     return dispatch(g, false, d->tile, (hipStream_t)stream);
 }

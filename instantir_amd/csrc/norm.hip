@@ -410,7 +410,8 @@ extern "C" int iir_groupnorm_nhwc(const void* X, int64_t ldx, void* Y, int64_t l
     const hipStream_t st = (hipStream_t)stream;
     // apply: ~1024 blocks over the batch
     int nblk = (1024 + R - 1) / R;
-    int ppb = (HW + nblk - 1) / nblk; if (ppb < 8) ppb = 8;
+    static const int min_ppb = getenv("IIR_GN_APPLY_MINPIX") ? atoi(getenv("IIR_GN_APPLY_MINPIX")) : 8;
+    int ppb = (HW + nblk - 1) / nblk; if (ppb < min_ppb) ppb = min_ppb;
     nblk = (HW + ppb - 1) / ppb;
     if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(nslab, R), dim3(256), 0, st, (const f16*)X, (long)ldx, HW, C, groups, pps, part);
     else hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(nslab, R), dim3(256), 0, st, (const f16*)X, (long)ldx, HW, C, groups, pps, part);

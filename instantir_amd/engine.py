@@ -149,6 +149,9 @@ class _Net:
         self._warena = None
         self.inkernel_prefetch = True
         self.fuse_qkv = os.environ.get("IIR_FUSE_QKV", "1") != "0"
+        # LayerNorm folded into the GEMMs either side of it (ops.LnFold; iir_gemm_desc.ln_stats_out / ln_stats_in): not with fp8
+        # operands (the activation would be rounded to 3 mantissa bits BEFORE its row mean is removed)
+        self.ln_fold = os.environ.get("IIR_LN_FOLD", "1") != "0" and not fp8_linear
         self._pack_encoder(sd)
 
     # ---- weight packing ---------------------------------------------------------------------
@@ -169,6 +172,11 @@ class _Net:
     def _pack_conv3(self, sd, path, cin_pad=None):
         self.w[path + ".w"] = conv_weight_nhwc(self._t(sd, path + ".weight"), cin_pad)
         self.w[path + ".b"] = self._t(sd, path + ".bias").contiguous()
+
+    def _pack_fold(self, dst, w32, sd, norm, bias=None, pair=None):
+        """`dst`.lnw / .lnb / .lncs: the Linear `w32` with the LayerNorm `norm` folded in (ops.LnFold)."""
+        f = ops.LnFold(w32, sd[norm + ".weight"].to(self.device), sd[norm + ".bias"].to(self.device), bias=bias, eps=1e-5, pair=pair)
+        self.w[dst + ".lnw"], self.w[dst + ".lnb"], self.w[dst + ".lncs"] = f.w, f.bias, f.colsum
 
     def _pack_norm(self, sd, path):
         self.w[path + ".g"] = self._t(sd, path + ".weight").contiguous()
@@ -196,9 +204,16 @@ class _Net:
             # (the softmax scale x log2 e is folded into the q rows: the attention kernel takes Q as it stands, `q_prescaled`)
             self.w[p + ".attn1.qkv.w"] = torch.cat([self._qw(sd, p + ".attn1.to_q.weight"), self._t(sd, p + ".attn1.to_k.weight"),
                                                     self._t(sd, p + ".attn1.to_v.weight")], 0).contiguous()
+            f32 = lambda n_: sd[n_].to(device=self.device, dtype=torch.float32)
+            qf = ops.attn_q_factor(self.cfg.head_dim ** -0.5)
+            if self.ln_fold:       # norm1 -> q|k|v, norm2 -> to_q, norm3 -> GEGLU proj: gamma into the weight, beta into a bias (fp32, one rounding)
+                self._pack_fold(p + ".attn1.qkv", torch.cat([f32(p + ".attn1.to_q.weight") * qf, f32(p + ".attn1.to_k.weight"),
+                                                             f32(p + ".attn1.to_v.weight")], 0), sd, p + ".norm1")
             self._pack_linear(sd, p + ".attn1.to_out.0")
             if self.cross:
                 self._pack_norm(sd, p + ".norm2")
+                if self.ln_fold:
+                    self._pack_fold(p + ".attn2.to_q", f32(p + ".attn2.to_q.weight") * qf, sd, p + ".norm2")
                 self.w[p + ".attn2.to_q.w"] = self._qw(sd, p + ".attn2.to_q.weight").contiguous()
                 self._pack_linear(sd, p + ".attn2.to_k")
                 self._pack_linear(sd, p + ".attn2.to_v")
@@ -213,6 +228,8 @@ class _Net:
             n = w1.shape[0] // 2
             self.w[p + ".ff1.w"] = pair_rows(w1[:n], w1[n:])          # GEGLU: value rows | gate rows
             self.w[p + ".ff1.b"] = pair_rows(b1[:n], b1[n:])
+            if self.ln_fold:
+                self._pack_fold(p + ".ff1", f32(p + ".ff.net.0.proj.weight"), sd, p + ".norm3", bias=f32(p + ".ff.net.0.proj.bias"), pair=pair_rows)
             self._pack_linear(sd, p + ".ff.net.2", p + ".ff2")
             if self.fp8_linear:
                 for key in ([p + ".attn1.qkv.w", p + ".attn1.to_out.0.w", p + ".ff1.w", p + ".ff2.w"]
@@ -365,33 +382,46 @@ class _Net:
         A.release(m)
         return out
 
-    def _tblock(self, p, h, R, T, heads, st, ada):
-        """One BasicTransformerBlock in place on h (R*T, C).  module/min_sdxl.py:541-562."""
+    def _tblock(self, p, h, R, T, heads, st, ada, lnst=None, last=False):
+        """One BasicTransformerBlock in place on h (R*T, C).  module/min_sdxl.py:541-562.
+        `lnst` (fp32 (parts, M, 2)): the LayerNorm partials of `h` left by the GEMM that wrote it.  When given, no LayerNorm
+        kernel runs in this block: each of the three norms is folded into the GEMM behind it (reads raw `h`, `ln_in`) and each
+        GEMM that writes `h` refreshes the partials (`ln_out`) for the next norm -- also the next block's, unless `last`."""
         self._unit(p)
         o, w, A = self.o, self.w, self.arena
         C = h.shape[1]
         M = R * T
         m = A.mark()
-        n = A.alloc(M, C)
+        fold = lnst is not None
+        n = None if fold else A.alloc(M, C)
         # -- self-attention (AttnProcessor2_0, attention_processor.py:370-402)
-        o.layernorm(h, n, w[p + ".norm1.g"], w[p + ".norm1.b"], 1e-5)
         qk = A.alloc(M, 2 * C)
         vt = A.alloc(C, M)
-        wqkv = w[p + ".attn1.qkv.w"]
-        if self.fuse_qkv:
-            o.gemm(n, wqkv, qk, prefetch=self._pf(wqkv), out_t=(vt, 2 * C))             # q | k, and V^T from the same launch
+        if fold:
+            wqkv = w[p + ".attn1.qkv.lnw"]
+            o.gemm(h, wqkv, qk, bias=w[p + ".attn1.qkv.lnb"], prefetch=self._pf(wqkv), out_t=(vt, 2 * C),
+                   ln_in=(lnst, w[p + ".attn1.qkv.lncs"], 1e-5))
         else:
-            o.gemm(n, wqkv[:2 * C], qk, prefetch=self._pf(wqkv))
-            o.gemm(wqkv[2 * C:], n, vt)                                                   # V^T = Wv . X^T (operands swapped)
+            o.layernorm(h, n, w[p + ".norm1.g"], w[p + ".norm1.b"], 1e-5)
+            wqkv = w[p + ".attn1.qkv.w"]
+            if self.fuse_qkv:
+                o.gemm(n, wqkv, qk, prefetch=self._pf(wqkv), out_t=(vt, 2 * C))             # q | k, and V^T from the same launch
+            else:
+                o.gemm(n, wqkv[:2 * C], qk, prefetch=self._pf(wqkv))
+                o.gemm(wqkv[2 * C:], n, vt)                                                   # V^T = Wv . X^T (operands swapped)
         a = A.alloc(M, C)
         o.attention(qk[:, :C], a, [(qk[:, C:], T, vt, T, T)], R, heads, T, q_prescaled=True)
         o.gemm(a, w[p + ".attn1.to_out.0.w"], h, bias=w[p + ".attn1.to_out.0.b"], res=h,
-               prefetch=self._pf(w[p + ".attn1.to_out.0.w"]))
+               prefetch=self._pf(w[p + ".attn1.to_out.0.w"]), ln_out=lnst)
         # -- decoupled cross-attention (TA_IPAttnProcessor2_0, attention_processor.py:1140-1195)
         if self.cross:
-            o.layernorm(h, n, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
             q = qk[:, :C]
-            o.gemm(n, w[p + ".attn2.to_q.w"], q, prefetch=self._pf(w[p + ".attn2.to_q.w"]))
+            if fold:
+                o.gemm(h, w[p + ".attn2.to_q.lnw"], q, bias=w[p + ".attn2.to_q.lnb"], prefetch=self._pf(w[p + ".attn2.to_q.lnw"]),
+                       ln_in=(lnst, w[p + ".attn2.to_q.lncs"], 1e-5))
+            else:
+                o.layernorm(h, n, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
+                o.gemm(n, w[p + ".attn2.to_q.w"], q, prefetch=self._pf(w[p + ".attn2.to_q.w"]))
             cfg = self.cfg
             nip, ipad = cfg.num_ip_tokens, (cfg.num_ip_tokens + 7) // 8 * 8
             kv = st["kv"][p]
@@ -399,12 +429,17 @@ class _Net:
             o.attention(q, a, [(kv["tk"], cfg.text_len, kv["tvt"], kv["tpad"], cfg.text_len), (ipk, nip, ipvt, ipad, nip)],
                         R, heads, T, q_prescaled=True)
             o.gemm(a, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h,
-                   prefetch=self._pf(w[p + ".attn2.to_out.0.w"]))
+                   prefetch=self._pf(w[p + ".attn2.to_out.0.w"]), ln_out=lnst)
         # -- GEGLU feed-forward (module/min_sdxl.py:502-528)
-        o.layernorm(h, n, w[p + ".norm3.g"], w[p + ".norm3.b"], 1e-5)
         f = A.alloc(M, 4 * C)
-        o.gemm(n, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.w"]))
-        o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]), splitk_ws=self._skws)
+        if fold:
+            o.gemm(h, w[p + ".ff1.lnw"], f, bias=w[p + ".ff1.lnb"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.lnw"]),
+                   ln_in=(lnst, w[p + ".ff1.lncs"], 1e-5))
+        else:
+            o.layernorm(h, n, w[p + ".norm3.g"], w[p + ".norm3.b"], 1e-5)
+            o.gemm(n, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.w"]))
+        o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]),
+               splitk_ws=None if fold else self._skws, ln_out=None if last else lnst)
         A.release(m)
 
     def _transformer(self, path, x, depth, R, H, W, st, ada, out=None):
@@ -418,9 +453,15 @@ class _Net:
         g = A.alloc(R * T, C)
         o.groupnorm(x, g, R, T, w[path + ".norm.g"], w[path + ".norm.b"], 1e-6, False, self.cfg.norm_groups, self._gnws)
         h = A.alloc(R * T, C)
-        o.gemm(g, w[path + ".proj_in.w"], h, bias=w[path + ".proj_in.b"])
+        # LayerNorm folding needs every GEMM that writes h (K = C: proj_in, to_out; K = 4C: ff2) to leave the same partials layout
+        lnst = None
+        if self.ln_fold and depth > 0:
+            parts = {ops.ln_parts(R * T, C, K) for K in (C, 4 * C)}
+            if len(parts) == 1 and 0 not in parts:
+                lnst = A.alloc(parts.pop() * R * T, 4).view(torch.float32).view(-1, R * T, 2)      # (parts, M, 2) fp32
+        o.gemm(g, w[path + ".proj_in.w"], h, bias=w[path + ".proj_in.b"], ln_out=lnst)
         for k in range(depth):
-            self._tblock(f"{path}.transformer_blocks.{k}", h, R, T, C // self.cfg.head_dim, st, ada)
+            self._tblock(f"{path}.transformer_blocks.{k}", h, R, T, C // self.cfg.head_dim, st, ada, lnst, last=k == depth - 1)
         o.gemm(h, w[path + ".proj_out.w"], out, bias=w[path + ".proj_out.b"], res=x)
         A.release(m)
         return out

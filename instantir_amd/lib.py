@@ -35,6 +35,8 @@ class GemmDesc(C.Structure):
         ("Ct", C.c_void_p), ("ldct", C.c_int64), ("tr_from", C.c_int32),
         ("dtype", C.c_int32), ("c_f32", C.c_int32),
         ("wscale", C.c_void_p),
+        ("ln_stats_out", C.c_void_p), ("ln_stats_in", C.c_void_p), ("ln_parts", C.c_int32), ("ln_part_cols", C.c_int32),
+        ("ln_eps", C.c_float), ("ln_colsum", C.c_void_p),
     ]
 
 
@@ -95,6 +97,7 @@ SIGNATURES = {
     "iir_gemm_uses_splitk": (C.c_int, [_I32, _I32, _I32, _I64]),
     "iir_gemm_pick_tile": (C.c_int, [_I32, _I32, _I32, _I32]),
     "iir_gemm_tile_bn": (C.c_int, [_I32]),
+    "iir_gemm_ln_parts": (C.c_int, [_I32, _I32, _I32]),
     "iir_conv2d_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "iir_attention_d64_f16": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "iir_groupnorm_nhwc_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _P]),

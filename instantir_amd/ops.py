@@ -133,11 +133,40 @@ def quantize_fp8_rows(w):
     return q, scale
 
 
+class LnFold:
+    """A LayerNorm folded into the nn.Linear that follows it (weight-pack time): `w` = W . diag(gamma) (fp16, or an Fp8Weight of
+    it), `colsum[n]` = sum_k w[n][k] in fp32 (of the STORED values, so the mean term cancels exactly), `bias` = b + W . beta."""
+
+    def __init__(self, weight, gamma, beta, bias=None, eps=1e-5, fp8=False, pair=None):
+        w32 = weight.float() * gamma.float()[None, :]
+        b32 = weight.float() @ beta.float() + (bias.float() if bias is not None else 0.0)
+        if pair is not None:                       # GEGLU: value rows | gate rows interleaved like the weight (packing.pair_rows)
+            n = w32.shape[0] // 2
+            w32, b32 = pair(w32[:n], w32[n:]), pair(b32[:n], b32[n:])
+        w16 = w32.to(torch.float16).contiguous()
+        if fp8:
+            q, sc = quantize_fp8_rows(w16)
+            self.w = Fp8Weight(q, sc)
+            self.colsum = (q.float().sum(dim=1) * sc).contiguous()
+        else:
+            self.w = w16
+            self.colsum = w16.float().sum(dim=1).contiguous()
+        self.bias = b32.to(torch.float16).contiguous()
+        self.eps = float(eps)
+
+
+def ln_parts(M, N, K):
+    """Partials per row the plain-epilogue, tile = 0 launch of (M, N, K) leaves in `ln_out` (0: it cannot)."""
+    return L.load().iir_gemm_ln_parts(M, N, K)
+
+
 def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
-         tile=0, prefetch=None, splitk_ws=None, out_t=None, wscale=None):
+         tile=0, prefetch=None, splitk_ws=None, out_t=None, wscale=None, ln_out=None, ln_in=None):
     """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues).
     out_t = (Ct, tr_from): output columns >= tr_from go, transposed, to Ct[n - tr_from, m]; `out` then is (M, tr_from).
-    wscale (fp32 (N,)): `w` holds fp8-E4M3 bytes (torch.float8_e4m3fn / uint8) with that per-row scale (fp8 MFMA)."""
+    wscale (fp32 (N,)): `w` holds fp8-E4M3 bytes (torch.float8_e4m3fn / uint8) with that per-row scale (fp8 MFMA).
+    ln_out (fp32 (parts, M, 2), parts = ln_parts(M, N, K)): also leave LayerNorm partials of the rows written.
+    ln_in = (partials (parts, M, 2) fp32, colsum (N,) fp32, eps): `a` holds raw rows, `w` / `bias` are an `LnFold`'s."""
     dt = a.dtype
     if isinstance(w, Fp8Weight):
         w, wscale = w.q, w.scale
@@ -180,6 +209,18 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     d.dtype, d.c_f32 = _DT[dt], int(c_f32)
     if wscale is not None:
         d.wscale = wscale.data_ptr()
+    if ln_out is not None:
+        if ln_out.dtype != torch.float32 or not ln_out.is_contiguous() or ln_out.dim() != 3 or ln_out.shape[1:] != (M, 2) \
+                or ln_out.shape[0] != ln_parts(M, N, K) or tile != 0:
+            raise ValueError("ln_out: contiguous fp32 (ln_parts(M, N, K), M, 2), tile = 0")
+        d.ln_stats_out = ln_out.data_ptr()
+    if ln_in is not None:
+        part, colsum, eps = ln_in
+        if part.dtype != torch.float32 or not part.is_contiguous() or part.dim() != 3 or part.shape[1:] != (M, 2) or K % part.shape[0]:
+            raise ValueError("ln_in partials: contiguous fp32 (parts, M, 2) with parts dividing K")
+        if colsum.dtype != torch.float32 or colsum.numel() != N or not colsum.is_contiguous():
+            raise ValueError("ln_in colsum: contiguous fp32 (N,)")
+        d.ln_stats_in, d.ln_colsum, d.ln_parts, d.ln_part_cols, d.ln_eps = part.data_ptr(), colsum.data_ptr(), part.shape[0], K // part.shape[0], eps
     if tile == 0:       # the library decides; resolve the same choice here only to NAME the launch for the profiler
         tile = 4 if splitk_ws is not None and L.load().iir_gemm_uses_splitk(M, N, K, splitk_ws.numel()) else auto_tile(M, N, epi != EPI_PLAIN, K)
     if prefetch is not None:

@@ -1,6 +1,8 @@
 """GPU: every HIP kernel, through the C ABI, against a plain PyTorch fp32 reference of the same op."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -457,3 +459,48 @@ def test_gemm_fp8_weights(dev, M, N, K, mode, tile):
     ops.gemm(x.to(dev), q.to(dev), out, bias=b.to(dev), res=res.to(dev), tile=tile, wscale=sc.to(dev))
     torch.cuda.synchronize()
     _close(out, full + b.float() + res.float(), rtol=4e-3, atol=4e-3, what="fp8 gemm")
+
+
+@pytest.mark.parametrize("M,C,N,geglu", [(2048, 1280, 1280, False), (2048, 1280, 2560, True), (8192, 640, 1920, False),
+                                         (512, 128, 384, False), (256, 320, 640, True)])
+def test_gemm_layernorm_fold(dev, M, C, N, geglu):
+    """LayerNorm without a LayerNorm launch: the GEMM that writes the residual stream leaves per-row (mean, M2) partials per
+    column tile (`ln_out`), the GEMM after the LayerNorm reads the RAW rows with gamma folded into its weight and applies
+    rstd * acc - rstd * mean * colsum + (bias + W beta) in its epilogue (`ln_in`).  Against torch: LayerNorm -> Linear [-> GEGLU]
+    in fp32 on the fp16 residual stream the producer wrote; rows carry a mean several times their spread."""
+    from instantir_amd import ops
+    from instantir_amd.packing import pair_rows
+    g = torch.Generator().manual_seed(M + C + N)
+    K0 = C                                                                 # the producer's K, as in the engine (to_out / proj_in)
+    a0, w0 = _rand(g, M, K0), _rand(g, C, K0, scale=K0 ** -0.5)
+    res = (_rand(g, M, C).float() + 4.0 * torch.randn(M, 1, generator=g)).half()          # per-row offsets: |mean| >> std
+    gamma, beta = (1.0 + 0.2 * torch.randn(C, generator=g)).half(), (0.3 * torch.randn(C, generator=g)).half()
+    w, b = _rand(g, N, C, scale=C ** -0.5), _rand(g, N)
+    parts = ops.ln_parts(M, C, K0)
+    assert 0 < parts <= 8 and C % parts == 0
+    h = torch.empty(M, C, dtype=torch.half, device=dev)
+    stats = torch.zeros(parts, M, 2, dtype=torch.float32, device=dev)
+    ops.gemm(a0.to(dev), w0.to(dev), h, res=res.to(dev), ln_out=stats)
+    torch.cuda.synchronize()
+    hf = h.float().cpu()
+    _close(h, a0.float() @ w0.float().T + res.float(), what="producer output")
+    # the partials merge to the row statistics of what was stored
+    cols = C // parts
+    blocks = hf.reshape(M, parts, cols)
+    np.testing.assert_allclose(stats[:, :, 0].cpu().T.numpy(), blocks.mean(-1).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(stats[:, :, 1].cpu().T.numpy(), ((blocks - blocks.mean(-1, keepdim=True)) ** 2).sum(-1).numpy(), rtol=2e-4, atol=1e-3)
+    y = F.layer_norm(hf, (C,), gamma.float(), beta.float(), 1e-5) @ w.float().T + b.float()
+    fold = ops.LnFold(w.to(dev), gamma.to(dev), beta.to(dev), bias=b.to(dev), eps=1e-5, pair=pair_rows if geglu else None)
+    if geglu:
+        want = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+        out = torch.empty(M, N // 2, dtype=torch.half, device=dev)
+        ops.gemm(h, fold.w, out, bias=fold.bias, epi=ops.EPI_GEGLU, ln_in=(stats, fold.colsum, fold.eps))
+    else:
+        want = y
+        out = torch.empty(M, N, dtype=torch.half, device=dev)
+        ops.gemm(h, fold.w, out, bias=fold.bias, ln_in=(stats, fold.colsum, fold.eps))
+    torch.cuda.synchronize()
+    tol = 8e-3 if geglu else 4e-3              # (GEGLU multiplies two quantities that each carry the fp16 / folding error)
+    _close(out, want, rtol=tol, atol=tol, what="LayerNorm-folded gemm")
+    with pytest.raises(ValueError):
+        ops.gemm(h, fold.w, out, bias=fold.bias, epi=ops.EPI_GEGLU if geglu else ops.EPI_PLAIN, ln_in=(stats[:, :M // 2], fold.colsum, fold.eps))
