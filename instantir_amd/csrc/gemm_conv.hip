@@ -282,9 +282,10 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         for (int s = 0; s < ST - 1; ++s)
             if (kt0 + s < nk) stage(kt0 + s, s);
     }
-    // LayerNorm statistics of this tile's rows: the producer's per-column-tile partials are FETCHED here, behind the first K
-    // tiles' LDS-DMA, and merged only after the K loop (a merge up front, with its load latency and divisions on two of the
-    // four waves, delayed every workgroup's first barrier: +12.8 us on the 2048 x 10240 x 1280 GEGLU projection).
+    // LayerNorm statistics of this tile's rows: the producer's per-column-tile partials are fetched here, behind the first K
+    // tiles' LDS-DMA, as ONE batch of unconditional loads, merged without a division per group and parked in LDS until the
+    // epilogue.  (Measured on the 2048 x 10240 x 1280 GEGLU projection: branchy loads + Chan merges with divisions up front
+    // +12.8 us; the partials held in 16 registers across the K loop and merged after it +9.4 us.)
     constexpr int MAXP = 8;
     float2 lnp_in[MAXP];
     const int ln_lt = LW ? tid - 64 * NW : tid;          // LW builds: the loader waves carry them
@@ -293,7 +294,23 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
 #pragma unroll
         for (int j = 0; j < MAXP; ++j)              // unconditional (clamped) loads: one straight-line batch; absent groups are masked at the merge
             lnp_in[j] = ((const float2*)g.ln_in)[(long)min(j, g.ln_parts - 1) * g.M + m];
-    }
+
+        // equal-count groups: mean = average of the group means, M2 = sum of the group M2 + cols * sum (mean_j - mean)^2
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) sm += j < g.ln_parts ? lnp_in[j].x : 0.f;
+        const float inv_p = 1.0f / (float)g.ln_parts, mean = sm * inv_p;
+        float m2 = 0.f, dev = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const float d = lnp_in[j].x - mean;
+            m2 += j < g.ln_parts ? lnp_in[j].y : 0.f;
+            dev += j < g.ln_parts ? d * d : 0.f;
+        }
+        const float var = (m2 + (float)g.ln_part_cols * dev) * inv_p / (float)g.ln_part_cols;
+        const float rstd = rsqrtf(var + g.ln_eps);
+        rowstat[ln_lt] = make_float2(rstd, -rstd * mean);
+        }
 
     // Software-pipelined across the barrier: the fragments of K-step 0 of tile kt+1 are fetched from LDS while the MFMAs of
     // K-step 1 of tile kt run, and the barrier that admits tile kt+1 sits between the two MFMA groups of tile kt -- so no
@@ -341,6 +358,19 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         else if (ST >= 3 && tiles_after >= 1) wait_vm_lgkm_and_barrier<(ST >= 3 ? LOADS : 0)>();
         else wait_vm_lgkm_and_barrier<0>();
     };
+    // what the epilogue needs per column (bias, LayerNorm column sums) is requested ahead of the LAST tile's MFMAs: fetched at
+    // the point of use, these loads' latency was exposed once per launch, on every wave at the same moment
+    f32x4 pre_c1[NI];
+    E4 pre_c0[NI];
+    auto preload_cols = [&]() {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nc = min(n0 + wn * WN + j * 16 + fq * 4, g.N - 4);       // clamped: lanes past the edge fetch a valid quad they never use
+            pre_c1[j] = g.ln_in ? *(const f32x4*)(g.ln_colsum + nc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (g.bias) pre_c0[j] = *(const E4*)((const E*)g.bias + nc);
+            else for (int t = 0; t < 4; ++t) pre_c0[j][t] = (E)0.f;
+        }
+    };
     E8 a0[MI], a1[MI];
     BF b0[NI], b1[NI];
     if constexpr (!LW) {
@@ -361,6 +391,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
             frags(cur, 0, a0, b0);
             mma(a1, b1);
         }
+        preload_cols();
         frags(cur, 1, a1, b1);
         mma(a0, b0);
         mma(a1, b1);
@@ -391,6 +422,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
             frags(cur, 0, a0, b0);
             mma(a1, b1);
         }
+        preload_cols();
         frags(cur, 1, a1, b1);
         mma(a0, b0);
         mma(a1, b1);
@@ -402,23 +434,6 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     // activation / GEGLU / SFT applied) goes through the now idle ring, and phase 2 writes whole rows, 16 B per lane,
     // adding the residual from equally coalesced loads.  (fp16 rounding before the residual add = torch's own order:
     // the Linear / Conv output is an fp16 tensor before `+ residual`.)
-    if (g.ln_in && ln_lt >= 0 && ln_lt < BM) {
-        // equal-count groups: mean = average of the group means, M2 = sum of the group M2 + cols * sum (mean_j - mean)^2
-        float sm = 0.f;
-#pragma unroll
-        for (int j = 0; j < MAXP; ++j) sm += j < g.ln_parts ? lnp_in[j].x : 0.f;
-        const float inv_p = 1.0f / (float)g.ln_parts, mean = sm * inv_p;
-        float m2 = 0.f, dev = 0.f;
-#pragma unroll
-        for (int j = 0; j < MAXP; ++j) {
-            const float d = lnp_in[j].x - mean;
-            m2 += j < g.ln_parts ? lnp_in[j].y : 0.f;
-            dev += j < g.ln_parts ? d * d : 0.f;
-        }
-        const float var = (m2 + (float)g.ln_part_cols * dev) * inv_p / (float)g.ln_part_cols;
-        const float rstd = rsqrtf(var + g.ln_eps);
-        rowstat[ln_lt] = make_float2(rstd, -rstd * mean);
-    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading the ring
 
     // ---- split-K: whichever of a tile's two workgroups finishes LAST adds the other's fp32 partial and runs the epilogue
@@ -491,8 +506,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
             if (n >= g.N) continue;
             float sc[4] = {1.f, 1.f, 1.f, 1.f}, c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
             if (W8) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) sc[t] = ws[t]; }
-            if (g.ln_in) { const f32x4 cs4 = *(const f32x4*)(g.ln_colsum + n); for (int t = 0; t < 4; ++t) c1[t] = cs4[t]; }
-            if (g.bias) { E4 b = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) c0[t] = (float)b[t]; }
+            for (int t = 0; t < 4; ++t) { c1[t] = pre_c1[j][t]; c0[t] = (float)pre_c0[j][t]; }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int lr = lrs[i];
@@ -518,8 +532,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
             const bool in_n = n < g.N;
             float sc[4] = {1.f, 1.f, 1.f, 1.f}, c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
             if (W8 && in_n) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) sc[t] = ws[t]; }
-            if (g.ln_in && in_n) { const f32x4 cs4 = *(const f32x4*)(g.ln_colsum + n); for (int t = 0; t < 4; ++t) c1[t] = cs4[t]; }
-            if (g.bias && in_n) { E4 ba = *(const E4*)(g.bias + n); for (int t = 0; t < 4; ++t) c0[t] = (float)ba[t]; }
+            for (int t = 0; t < 4; ++t) { c1[t] = pre_c1[j][t]; c0[t] = (float)pre_c0[j][t]; }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int lr = lrs[i];
