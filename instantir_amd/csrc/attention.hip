@@ -243,51 +243,75 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
 //     separate instantiations, so the steady-state tile body is one branch-free basic block the scheduler can interleave
 //     (the first-generation loop carried 66 s_nop hazard pads per tile between its cvt_pk and MFMA instructions).
 // Cross-half row maximum by v_permlane32_swap (VALU) instead of ds_bpermute.
+
 constexpr float THR = 5.0f;
 
-template <bool FIRST>
-__device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const f16x8 (&qf)[4], const f32x16& c0, const f32x16& c1,
+// One 64-key tile as TWO online-softmax steps of 32 keys (third form, round 2 late).  The 16 MFMAs of a tile used to sit in two
+// groups either side of the whole tile's vector work (row maximum over all 64 keys before the first exponential): a serial
+// chain  8 MFMA -> softmax -> 8 MFMA  in which neither pipe ever had the other's work to overlap with (5.3: a lone workgroup
+// needs ~2000 cycles per tile for 512 cycles of MFMA).  Per half, the dependences are: scores(b) need only the maximum left by
+// half a; P.V of half a needs only P(a).  So the score MFMAs of half b are issued next to the exponentials of half a, and the
+// P.V MFMAs of half a next to the maximum / exponentials of half b -- same registers (the two 16-register score blocks), same
+// LDS traffic, two threshold tests per tile instead of one.
+//   FIRST: the first tile of a KV segment (no maximum yet, accumulators empty).  MASKED: c0 / c1 are per-half C operands built by
+//   the caller from -m (and -inf for hidden keys) instead of the live -m vector, so a rescale in half a must correct c1 too.
+template <bool FIRST, bool MASKED>
+__device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const f16x8 (&qf)[4], f32x16& c0, f32x16& c1,
                                           f32x16& negm, float& m, float& l, f32x16 (&o)[2], int qi, int hh) {
-    // ---- S'^T = K . (c Q)^T + C   (2 blocks of 32 keys; keys on accumulator rows, query on the lane).  C is -m of the
-    //      lane's query in every register (0 on a segment's first tile), or -inf in the registers of masked keys: the mask
-    //      costs the tile body nothing.
-    f32x16 sacc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    auto scores = [&](int kb, const f32x16& c) {
         const char* krow = kt + (kb * 32 + qi) * 128;
         const int sw = qi & 7;
         f16x8 kf = *(const f16x8*)(krow + ((hh ^ sw) * 16));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], kb ? c1 : c0, 0, 0, 0);
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], c, 0, 0, 0);
 #pragma unroll
         for (int ks = 1; ks < 4; ++ks) {
             kf = *(const f16x8*)(krow + (((2 * ks + hh) ^ sw) * 16));
-            sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], acc, 0, 0, 0);
         }
-    }
-    // ---- tile maximum of the row (relative to the running maximum), both lane halves
-    float mx, mxb;                                  // two independent v_max3 chains (latency, not count, is what a lone wave pays)
-    mx = fmaxf(sacc[0][0], sacc[0][1]);
-    mxb = fmaxf(sacc[1][0], sacc[1][1]);
+        return acc;
+    };
+    auto row_max = [&](const f32x16& a) {
+        float mx = fmaxf(a[0], a[1]), mxb = fmaxf(a[2], a[3]);      // two independent chains
 #pragma unroll
-    for (int r = 2; r < 16; r += 2) {
-        mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[0][r + 1]);
-        mxb = fmaxf(fmaxf(mxb, sacc[1][r]), sacc[1][r + 1]);
-    }
-    mx = fmaxf(mx, mxb);
-    {
+        for (int r = 4; r < 16; r += 4) {
+            mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
+            mxb = fmaxf(fmaxf(mxb, a[r + 2]), a[r + 3]);
+        }
+        mx = fmaxf(mx, mxb);
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    if (FIRST) {
-        m = mx;                                     // (a row with no visible key cannot occur: key 0 is visible to every query)
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+    // P = 2^S' of one half, its row sum, and O^T += V^T . P^T for the half's two k-steps.  The K rows of the tile were staged in
+    // the order that makes accumulator register 8*sp + j of lane half hh the score of key 32*kb + 16*sp + 8*hh + j (see `stage`),
+    // so the packed P registers are the B operand as they stand and the matching V^T fragment is ONE 16-byte read.
+    auto exp_pv = [&](int kb, f32x16& a, bool zero_o) {
+        float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(a[r]);
+            a[r] = p;
+            ls[r & 3] += p;
+        }
+        l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] -= mx;
+        for (int sp = 0; sp < 2; ++sp) {
+            f16x8 pf;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -mx;
-    } else if (__any(mx > THR)) {
-        const float delta = fmaxf(mx, 0.f);         // rows whose maximum did not grow keep delta = 0, alpha = 1 exactly
+            for (int j = 0; j < 8; ++j) pf[j] = (f16)a[8 * sp + j];
+            const int chunk = kb * 4 + sp * 2 + hh;                  // 16-byte chunk of the V^T row: keys 8*chunk + [0,8)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int d = db * 32 + qi;
+                const f16x8 vf = *(const f16x8*)(vt + d * 128 + ((chunk ^ ((d >> 1) & 7)) * 16));
+                if (zero_o && sp == 0) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+                else o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[db], 0, 0, 0);
+            }
+        }
+    };
+    // raise the running maximum by delta (rows whose maximum did not grow keep delta = 0, alpha = 1 exactly): every quantity at
+    // the old maximum is scaled by the same 2^-delta once
+    auto rescale = [&](float mx, f32x16& a, bool fix_c1) {
+        const float delta = fmaxf(mx, 0.f);
         const float alpha = __builtin_amdgcn_exp2f(-delta);
         l *= alpha;
 #pragma unroll
@@ -295,50 +319,125 @@ __device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
+        for (int r = 0; r < 16; ++r) a[r] -= delta;
         m += delta;
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[r] = -m;
-    }
-    // ---- P = 2^S', row sums (this lane's half of the keys)
-    float ls[4] = {0.f, 0.f, 0.f, 0.f};             // four independent partial sums
+        if (fix_c1) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(sacc[kb][r]);
-            sacc[kb][r] = p;
-            ls[r & 3] += p;
+            for (int r = 0; r < 16; ++r) c1[r] -= delta;             // (-inf stays -inf)
         }
-    l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
-    // ---- O^T += V^T . P^T : k-step (kb, sp).  The K rows of the tile were staged in the order that makes accumulator
-    //      register 8*sp + j of lane half hh the score of key 32*kb + 16*sp + 8*hh + j (see `stage`), so the packed P
-    //      registers are the B operand as they stand and the matching V^T fragment is ONE 16-byte read of 8 consecutive keys.
+    };
+
+    // ---- half a: scores, maximum
+    f32x16 sa = scores(0, c0);
+    {
+        const float mx = row_max(sa);
+        if (FIRST) {
+            m = mx;                                 // (a row with no visible key cannot occur: key 0 is visible to every query)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+            for (int r = 0; r < 16; ++r) sa[r] -= mx;
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            f16x8 pf;
+            for (int r = 0; r < 16; ++r) negm[r] = -mx;
+            if (MASKED) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (f16)sacc[kb][8 * sp + j];
-            const int chunk = kb * 4 + sp * 2 + hh;                  // 16-byte chunk of the V^T row: keys 8*chunk + [0,8)
+                for (int r = 0; r < 16; ++r) c1[r] -= mx;            // the caller built c1 against m = 0
+            }
+        } else if (__any(mx > THR)) rescale(mx, sa, MASKED);
+    }
+    // ---- region 2: half b's four score MFMAs, each followed by a quarter of half a's exponentials / sums / packing
+    //      (explicit order: the scheduler clustered the MFMAs when left alone)
+    f16x8 pa[2], pb[2];
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x16 sb;
+    {
+        const char* krow = kt + (32 + qi) * 128;
+        const int sw = qi & 7;
+        f16x8 kf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const f16x8*)(krow + (((2 * ks + hh) ^ sw) * 16));
+        // (no sched_barrier: pure exp / MFMA intrinsics are not ordered by it)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks ? sb : (MASKED ? c1 : negm), 0, 0, 0);
+#pragma unroll
+            for (int r = 4 * ks; r < 4 * ks + 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sa[r]);
+                sa[r] = p;
+                ls[r & 3] += p;
+            }
+            if (ks & 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pa[ks >> 1][j] = (f16)sa[8 * (ks >> 1) + j];
+            }
+
+        }
+    }
+    {
+        const float mx = row_max(sb);
+        if (__any(mx > THR)) {
+            // half a's P is not in O yet: it is scaled with everything else at the old maximum
+            const float delta = fmaxf(mx, 0.f);
+            const f16 ah = (f16)__builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pa[sp][j] = pa[sp][j] * ah;
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ls[t] *= alpha;
+            rescale(mx, sb, false);
+        }
+    }
+    // ---- region 3: half a's four P.V MFMAs, each followed by a quarter of half b's exponentials; then half b's P.V
+    {
+        f16x8 vf[4];
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int d = db * 32 + qi;
-                const f16x8 vf = *(const f16x8*)(vt + d * 128 + ((chunk ^ ((d >> 1) & 7)) * 16));
-                if (FIRST && kb == 0 && sp == 0) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-                else o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[db], 0, 0, 0);
+                const int d = db * 32 + qi, chunk = sp * 2 + hh;
+                vf[sp * 2 + db] = *(const f16x8*)(vt + d * 128 + ((chunk ^ ((d >> 1) & 7)) * 16));
             }
+        // (no sched_barrier: pure exp / MFMA intrinsics are not ordered by it)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sp = q >> 1, db = q & 1;
+            if (FIRST && sp == 0) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[q], pa[sp], (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+            else o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[q], pa[sp], o[db], 0, 0, 0);
+#pragma unroll
+            for (int r = 4 * q; r < 4 * q + 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sb[r]);
+                sb[r] = p;
+                ls[r & 3] += p;
+            }
+            if (q & 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[q >> 1][j] = (f16)sb[8 * (q >> 1) + j];
+            }
+
         }
+        l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int d = db * 32 + qi, chunk = 4 + sp * 2 + hh;
+                const f16x8 v2 = *(const f16x8*)(vt + d * 128 + ((chunk ^ ((d >> 1) & 7)) * 16));
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v2, pb[sp], o[db], 0, 0, 0);
+            }
+    }
 }
 
-template <int WPS>
+// NB: depth of the K / V^T tile ring.  With two buffers the loads of tile t+1 have one tile's compute (~0.5 us for a workgroup
+// alone on its CU) to land; the 320-workgroup level-2 launches and the cross-attention launches waited ~1 us per tile on them.
+// NB - 1 tiles are in flight; the wait at the end of tile t is counted (`vmcnt(4 * tiles still allowed in flight)`), 4 LDS-DMA
+// instructions per wave and tile.
+template <int WPS, int NB>
 __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];
-    char* Ks = smem;                    // [2][64 keys][128 B]
-    char* Vs = smem + 2 * KT * 128;     // [2][64 d][128 B]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                    // [NB][64 keys][128 B]
+    char* Vs = smem + NB * KT * 128;    // [NB][64 d][128 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,9 +501,17 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
         f32x16 negm, o[2];
         const bool ragged = (s.Tkv % KT) != 0;
 
-        stage(0, 0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i)
+            if (i < ntiles) stage(i, i);
+        // wait until at most `allowed` later tiles are still in flight (4 LDS-DMA instructions each), then barrier
+        auto wait_tiles = [&](int allowed) {
+            if (NB >= 4 && allowed >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);
+            else if (NB >= 3 && allowed >= 1) __builtin_amdgcn_s_waitcnt(0x0F74);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        };
+        wait_tiles(min(NB - 2, ntiles - 1));
         // C operand of a masked tile: `base` (0 on the first tile, -m afterwards) for visible keys, -inf for keys past the
         // end of the segment or (causal) after the query.  Built outside the steady-state loop: ragged tail / CLIP text only.
         auto build_mask = [&](int t, float base, f32x16& c0, f32x16& c1) {
@@ -420,34 +527,40 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
                     if (kb) c1[r] = v; else c0[r] = v;
                 }
         };
-        auto begin_tile = [&](int t) { if (t + 1 < ntiles) stage(t + 1, (t & 1) ^ 1); };
-        auto end_tile = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); };
+        int buf = 0;                                            // ring slot of the current tile
+        auto begin_tile = [&](int t) { if (t + NB - 1 < ntiles) stage(t + NB - 1, buf == 0 ? NB - 1 : buf - 1); };   // (t + NB - 1) % NB
+        auto end_tile = [&](int t) {                            // tile t + 1 landed for every wave, everyone done with tile t
+            wait_tiles(max(0, min(NB - 2, ntiles - 2 - t)));
+            buf = buf + 1 == NB ? 0 : buf + 1;
+        };
         const bool mask_all = g.causal != 0;
         {   // tile 0: accumulators empty, no maximum yet
             f32x16 c0, c1;
             begin_tile(0);
-            if (mask_all || (ragged && ntiles == 1)) build_mask(0, 0.f, c0, c1);
-            else {
+            if (mask_all || (ragged && ntiles == 1)) {
+                build_mask(0, 0.f, c0, c1);
+                attn_tile<true, true>(Ks, Vs, qf, c0, c1, negm, m, l, o, qi, hh);
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+                for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+                attn_tile<true, false>(Ks, Vs, qf, c0, c0, negm, m, l, o, qi, hh);
             }
-            attn_tile<true>(Ks, Vs, qf, c0, c1, negm, m, l, o, qi, hh);
-            end_tile();
+            end_tile(0);
         }
         if (!mask_all) {
             const int nfull = ragged ? ntiles - 1 : ntiles;
             for (int t = 1; t < nfull; ++t) {                      // steady state: one branch-free body
                 begin_tile(t);
-                attn_tile<false>(Ks + (t & 1) * KT * 128, Vs + (t & 1) * KT * 128, qf, negm, negm, negm, m, l, o, qi, hh);
-                end_tile();
+                attn_tile<false, false>(Ks + buf * KT * 128, Vs + buf * KT * 128, qf, negm, negm, negm, m, l, o, qi, hh);
+                end_tile(t);
             }
         }
         for (int t = mask_all ? 1 : (ragged && ntiles > 1 ? ntiles - 1 : ntiles); t < ntiles; ++t) {      // masked tiles
             f32x16 c0, c1;
             begin_tile(t);
             build_mask(t, -m, c0, c1);
-            attn_tile<false>(Ks + (t & 1) * KT * 128, Vs + (t & 1) * KT * 128, qf, c0, c1, negm, m, l, o, qi, hh);
-            end_tile();
+            attn_tile<false, true>(Ks + buf * KT * 128, Vs + buf * KT * 128, qf, c0, c1, negm, m, l, o, qi, hh);
+            end_tile(t);
         }
         const float ltot = l + __shfl_xor(l, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(ltot);
@@ -514,10 +627,17 @@ extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
     // waves per SIMD (no spills); default 0 = second generation, the 2-wave build when the grid cannot put more than two
     // workgroups on a CU anyway (measured: T = 1024 x 40 pairs 24.8 vs 27.2 us; T = 8192 462 vs 453 us).
     static const int version = getenv("IIR_ATTN_V") ? atoi(getenv("IIR_ATTN_V")) : 0;
+    // (ring depths 3 and 4 were built and measured: no change on any of the step's shapes, `profiles/r02_attn_ring_depth.log`;
+    //  only the two-buffer instantiations are compiled)
+    auto launch2 = [&](auto kern, int nb) {
+        const size_t lds = (size_t)nb * 2 * KT * 128;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        iir_launch(kern, grid, dim3(256), lds, (hipStream_t)stream, g);
+    };
     if (version == 1) {
         if (g.qpre) g.c = 1.0f;
         iir_launch(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
-    } else if (version == 3 || (version == 0 && grid.x <= 512)) iir_launch(attn_kernel2<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
-    else iir_launch(attn_kernel2<3>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    } else if (version == 3 || (version == 0 && grid.x <= 512)) launch2(attn_kernel2<2, 2>, 2);
+    else launch2(attn_kernel2<3, 2>, 2);
     return iir_launch_status();
 }
