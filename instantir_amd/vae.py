@@ -249,6 +249,15 @@ class HipVAE:
         """image (B,3,H,W) in [-1,1]; eps (B,4,H/8,W/8) the N(0,1) draw of `latent_dist.sample()`.
         Returns the UNscaled latent mean + std * eps (fp32)."""
         image = image.to(self.device, torch.float32).contiguous()
+        big = image.shape[-1] > self.tile_sample_size or image.shape[-2] > self.tile_sample_size
+        mom = self.moments_tiled(image, self.tile_sample_size, self.tile_overlap_factor) if self.use_tiling and big else self.moments(image)
+        mean, logvar = mom[:, :4], mom[:, 4:]
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))           # module/diffusers_vae/vae.py:774-777,792
+        return mean + std * eps.to(self.device, torch.float32)
+
+    def moments(self, image: torch.Tensor) -> torch.Tensor:
+        """encoder + quant_conv: the 8-channel posterior moments (B, 8, H/8, W/8), fp32."""
+        image = image.to(self.device, torch.float32).contiguous()
         B, _, H, W = image.shape
         xin = torch.zeros(B * H * W, CPAD, dtype=self._E, device=self.device)
         ops.pack_latent(image, xin)
@@ -256,9 +265,33 @@ class HipVAE:
         self._run(("enc", B, H, W), lambda: self._encode(xin, B, H, W, mom))
         if not torch.isfinite(mom).all():
             raise FloatingPointError(f"VAE encode produced non-finite moments (activation overflow in the {self.dtype_name} build)")
-        mean, logvar = mom[:, :4], mom[:, 4:]
-        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))           # module/diffusers_vae/vae.py:774-777,792
-        return mean + std * eps.to(self.device, torch.float32)
+        return mom
+
+    def moments_tiled(self, image: torch.Tensor, sample_size: int = 1024, overlap: float = 0.25) -> torch.Tensor:
+        """`AutoencoderKL.tiled_encode` (module/diffusers_vae/autoencoder_kl.py:323-375): overlapping pixel tiles of `sample_size`
+        (stride 768 px for SDXL), each encoded on its own; the MOMENTS are blended over tile_latent * overlap (32) rows /
+        columns against the already blended upper / left neighbour, cropped to 96 and concatenated."""
+        tl = sample_size // 8
+        stride = int(sample_size * (1 - overlap))
+        ext = int(tl * overlap)
+        limit = tl - ext
+        rows = []
+        for i in range(0, image.shape[2], stride):
+            rows.append([self.moments(image[:, :, i:i + sample_size, j:j + sample_size].contiguous()).contiguous()
+                         for j in range(0, image.shape[3], stride)])
+        out_rows = []
+        for i, row in enumerate(rows):
+            parts = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    up = rows[i - 1][j]
+                    ops.blend_tiles(up, tile, min(up.shape[2], tile.shape[2], ext), True)
+                if j > 0:
+                    left = row[j - 1]
+                    ops.blend_tiles(left, tile, min(left.shape[3], tile.shape[3], ext), False)
+                parts.append(tile[:, :, :limit, :limit])
+            out_rows.append(torch.cat(parts, dim=3))
+        return torch.cat(out_rows, dim=2)
 
     def encode_to_latent(self, image, eps=None, generator=None):
         """`vae.encode(image).latent_dist.sample() * scaling_factor` (pipelines/sdxl_instantir.py:1375-1376)."""

@@ -66,6 +66,30 @@ def encode(P, vc, img, eps):
     """AutoencoderKL.encode(...).latent_dist.sample() with the N(0,1) draw passed explicitly
     (vae.py:137-195 Encoder.forward; :771-793 posterior; the reference draws from the global RNG,
     SURVEY Appendix B item 1).  Returns the UNscaled latent."""
+    return sample_moments(moments(P, vc, img), eps)
+
+
+def sample_moments(mom, eps):
+    mean, logvar = torch.chunk(mom, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    return mean + std * eps
+
+
+def encode_tiled(P, vc, img, eps, sample_size=1024, overlap=0.25):
+    """AutoencoderKL.tiled_encode, module/diffusers_vae/autoencoder_kl.py:323-375: overlapping PIXEL tiles of `sample_size`
+    (stride sample_size * (1 - overlap)), each through encoder + quant_conv on its own; the 8-channel MOMENTS are blended over
+    tile_latent * overlap rows / columns against the upper / left neighbour, cropped to tile_latent * (1 - overlap) and
+    concatenated; the posterior is sampled from the blended moments."""
+    tl = sample_size // 8
+    stride = int(sample_size * (1 - overlap))
+    ext = int(tl * overlap)
+    limit = tl - ext
+    rows = [[moments(P, vc, img[:, :, i:i + sample_size, j:j + sample_size]) for j in range(0, img.shape[3], stride)]
+            for i in range(0, img.shape[2], stride)]
+    return sample_moments(_blend_rows(rows, ext, limit), eps)
+
+
+def moments(P, vc, img):
     g = vc.norm_groups
     x = conv2d(P, "encoder.conv_in", img)
     n = len(vc.block_out_channels)
@@ -78,10 +102,7 @@ def encode(P, vc, img, eps):
     x = _mid(P, "encoder.mid_block", x, g)
     x = F.silu(group_norm(P, "encoder.conv_norm_out", x, g, 1e-6))
     x = conv2d(P, "encoder.conv_out", x)
-    x = conv2d(P, "quant_conv", x, padding=0)
-    mean, logvar = torch.chunk(x, 2, dim=1)
-    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
-    return mean + std * eps
+    return conv2d(P, "quant_conv", x, padding=0)
 
 
 def decode_tiled(P, vc, z, sample_size=1024, overlap=0.25):
@@ -90,7 +111,11 @@ def decode_tiled(P, vc, z, sample_size=1024, overlap=0.25):
     stride, ext = int(tl * (1 - overlap)), int(sample_size * overlap)
     limit = sample_size - ext
     rows = [[decode(P, vc, z[:, :, i:i + tl, j:j + tl]) for j in range(0, z.shape[3], stride)] for i in range(0, z.shape[2], stride)]
+    return _blend_rows(rows, ext, limit)
 
+
+def _blend_rows(rows, ext, limit):
+    """blend_v / blend_h against the already blended upper / left tile, crop, concatenate (autoencoder_kl.py:311-321,359-371,406-418)."""
     def blend_v(a, b, e):
         e = min(a.shape[2], b.shape[2], e)
         for y in range(e):

@@ -81,3 +81,43 @@ def test_full_sdxl_shapes(size, guidance, steps, ts):
     from conftest import record_psnr
     record_psnr(f"fullsize.{size}px.cfg{guidance}.steps{steps}" + ("" if ts is None else f".t{ts[0]}"), p)
     assert p >= 50.0, p
+
+
+def test_config3_2048px_end_to_end():
+    """BASELINE configs[3] end to end at full SDXL shapes: a 2048x2048 pixel input through VAE encode, the loop with
+    `control_guidance_end` closing the Aggregator gate for the last two steps (all three loop phases at T = 16384 / 32768-token
+    attention), and the TILED decode (`pipe.vae.enable_tiling()`, module/diffusers_vae/autoencoder_kl.py:130-157) -- the
+    untiled decode cannot serve this size (its mid-block attention would need a 65536-wide softmax) and says so.  The oracle needs
+    ~8 min per step here (`tools/parity_fullsize.py --size 2048`, log under profiles/), so this driver-run case checks properties:
+    finite, right shape and range, one preview per previewing step, and step-for-step equality with a second run."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from instantir_amd import lib, weights as W
+    from instantir_amd.config import UNetConfig, VAEConfig
+    from instantir_amd.pipeline import InstantIRPipeline
+    from instantir_amd.schedulers import DDIMScheduler, LCMSingleStepScheduler
+    from instantir_amd.vae import HipVAE
+    lib.load()
+    dev = torch.device("cuda:0")
+    cfg, vc = UNetConfig.sdxl(), VAEConfig.sdxl()
+    vae = HipVAE(vc, W.synth_state_dict(W.vae_decoder_specs(vc) + W.vae_encoder_specs(vc), 1237, device=dev), dev)
+    pipe = InstantIRPipeline(cfg, W.synth_state_dict(W.unet_specs(cfg), 1234, device=dev), scheduler=DDIMScheduler(), vae=vae, device=dev)
+    pipe.aggregator.load_state_dict(W.synth_state_dict(W.aggregator_specs(cfg), 1235, device=dev))
+    pipe.prepare_previewers(W.synth_state_dict(W.lora_specs(cfg), 1236, device=dev), lora_alpha=8)
+    g = torch.Generator().manual_seed(7)
+    px = torch.rand(1, 3, 2048, 2048, generator=g)
+    kw = dict(image=px, prompt_embeds=torch.randn(1, 77, 2048, generator=g), pooled_prompt_embeds=torch.randn(1, 1280, generator=g),
+              negative_prompt_embeds=torch.randn(1, 77, 2048, generator=g), negative_pooled_prompt_embeds=torch.randn(1, 1280, generator=g),
+              ip_adapter_image_embeds=[torch.randn(2, 1, 257, 1024, generator=g)], num_inference_steps=4, guidance_scale=7.0,
+              control_guidance_end=0.7, previewer_scheduler=LCMSingleStepScheduler.from_config(pipe.scheduler.config),
+              init_noise=torch.randn(1, 4, 256, 256, generator=g), vae_noise=torch.randn(1, 4, 256, 256, generator=g),
+              output_type="pt", return_dict=False, save_preview_row=True)
+    with pytest.raises(ValueError):                       # untiled decode of a 256x256 latent: refused with the reason
+        pipe(**kw)
+    pipe.vae.enable_tiling()
+    img, row = pipe(**kw)
+    assert img.shape == (1, 3, 2048, 2048) and torch.isfinite(img).all() and 0.0 <= img.min().item() and img.max().item() <= 1.0
+    assert img.std().item() > 1e-3                         # not a constant image
+    assert len(row) == 2                                   # the gate closes when (i + 1) / 4 > 0.7 (:1447-1450): steps 0, 1 preview, steps 2, 3 run without previewer / Aggregator
+    img2, _ = pipe(**kw)
+    assert torch.equal(img, img2)                          # bit-reproducible run to run (no atomics anywhere on the path)

@@ -219,6 +219,28 @@ def test_vae_tiled_decode_matches_oracle(vae_env):
     assert torch.equal(tiled, (got / 2 + 0.5).clamp(0, 1)) and not torch.equal(tiled, plain)
 
 
+def test_vae_tiled_encode_matches_oracle(vae_env):
+    """Tiled encode (`enable_tiling()` + an input above the tile: module/diffusers_vae/autoencoder_kl.py:256-257,323-375):
+    3 x 3 overlapping pixel tiles at the tiny geometry (tile 128 px = 16 latent px, stride 96 px, moments blended over 4 latent
+    rows / columns, crop 12; ragged last row / column), posterior sampled from the blended moments."""
+    from oracle import vae as OV
+    vc, sd, hv = vae_env
+    g = torch.Generator().manual_seed(8)
+    img = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    eps = torch.randn(1, 4, 32, 32, generator=g)
+    want = OV.encode_tiled({k: v.float() for k, v in sd.items()}, vc, img, eps, sample_size=128)
+    hv.tile_sample_size = 128
+    plain = hv.encode(img, eps).cpu()
+    hv.enable_tiling()
+    got = hv.encode(img, eps).cpu()
+    hv.disable_tiling()
+    hv.tile_sample_size = 1024
+    assert got.shape == want.shape == (1, 4, 32, 32)
+    p = psnr(got, want)
+    assert torch.isfinite(got).all() and p > BAR[hv.dtype], p
+    assert not torch.equal(got, plain)                     # the tiled result differs from the untiled one, as in the reference
+
+
 def test_vae_activation_overflow(dev):
     """SDXL's VAE carries activations beyond the fp16 range, which is why the reference upcasts it to fp32
     (pipelines/sdxl_instantir.py:984-1001).  With conv_in scaled so the mid block runs at ~1e5: the bf16 build still
