@@ -631,7 +631,7 @@ extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
     //  only the two-buffer instantiations are compiled)
     auto launch2 = [&](auto kern, int nb) {
         const size_t lds = (size_t)nb * 2 * KT * 128;
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // (32 KB of dynamic LDS: below the 64 KB that needs hipFuncAttributeMaxDynamicSharedMemorySize)
         iir_launch(kern, grid, dim3(256), lds, (hipStream_t)stream, g);
     };
     if (version == 1) {

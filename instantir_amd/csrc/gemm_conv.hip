@@ -738,29 +738,30 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     }
     const dim3 grid(8 * g.rm * g.rn * (g.splitk == 2 ? 2 : 1)), block(128 * WAVES_M * (LW ? 2 : 1));
     if constexpr (W8) {
-        static bool attr_8 = false;
-        if (!attr_8) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_8 = true; }
+        static const hipError_t attr_8 = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (function-local static: initialised once, thread-safe)
+        (void)attr_8;
         iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, grid, block, lds, stream, g);
         return iir_launch_status();
     } else if constexpr (LW) {
         if (g.splitk == 2) return IIR_EINVAL;
-        static bool attr_l = false, attr_lc = false;
         if (conv) {
-            if (!attr_lc) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lc = true; }
+            static const hipError_t attr_lc = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)attr_lc;
             iir_launch(gemm_kernel<E, BM, BN, ST, true, WAVES_M, false, true>, grid, block, lds, stream, g);
         } else {
-            if (!attr_l) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_l = true; }
+            static const hipError_t attr_l = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)attr_l;
             iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, grid, block, lds, stream, g);
         }
         return iir_launch_status();
     } else
     if (conv) {
-        static bool attr_c = false;
-        if (!attr_c) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_c = true; }
+        static const hipError_t attr_c = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (function-local static: initialised once, thread-safe)
+        (void)attr_c;
         iir_launch(gemm_kernel<E, BM, BN, ST, true, WAVES_M>, grid, block, lds, stream, g);
     } else {
-        static bool attr_g = false;
-        if (!attr_g) { (void)hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_g = true; }
+        static const hipError_t attr_g = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (function-local static: initialised once, thread-safe)
+        (void)attr_g;
         iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M>, grid, block, lds, stream, g);
     }
     return iir_launch_status();

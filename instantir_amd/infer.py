@@ -177,8 +177,11 @@ def main(args, device, rank=0, world=1):
             out_sizes.append(out_size)
         if len({im.size for im in lq}) != 1:
             raise ValueError("images of one batch must share a size after resize_img (use --width/--height or --batch_size 1)")
-        prompt = " ".join(args.prompt) if args.prompt else DEFAULT_PROMPT
-        neg = " ".join(args.neg_prompt) if args.neg_prompt else DEFAULT_NEG_PROMPT
+        # infer.py:191-210: `--prompt` / `--neg_prompt` are nargs="*" LISTS and the reference multiplies the list by the batch
+        # (`prompt = args.prompt * len(lq)`): `--prompt "a photo" "a drawing"` with one image asks for two restorations, one per
+        # entry; with several images AND several entries the pipeline's own batch check (:1316-1319) rejects the call.
+        prompts = (list(args.prompt) if args.prompt else [DEFAULT_PROMPT]) * len(lq)
+        negs = (list(args.neg_prompt) if args.neg_prompt else [DEFAULT_NEG_PROMPT]) * len(lq)
         kw = dict(image=lq, num_inference_steps=args.num_inference_steps, generator=generator, guidance_scale=args.cfg,
                   previewer_scheduler=lcm_scheduler, preview_start=args.preview_start, control_guidance_end=args.creative_start)
         if args.synthetic:
@@ -190,7 +193,7 @@ def main(args, device, rank=0, world=1):
                       negative_pooled_prompt_embeds=torch.randn(n, cfg.pooled_dim, generator=g),
                       ip_adapter_image_embeds=[torch.randn(2 if args.cfg > 1 else 1, n, cfg.resampler.seq_len, cfg.resampler.embedding_dim, generator=g)])
         else:
-            kw.update(prompt=[prompt] * len(lq), negative_prompt=[neg] * len(lq), ip_adapter_image=lq)
+            kw.update(prompt=prompts, negative_prompt=negs, ip_adapter_image=lq)
         images = pipe(**kw).images
         for i, (rec, out_size) in enumerate(zip(images, out_sizes)):
             rec.resize([out_size[0], out_size[1]], Image.BILINEAR).save(f"{out_dir}/{lq_batch[i]}")
