@@ -321,8 +321,12 @@ __device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] -= delta;
         m += delta;
+        {   // in place (tied operand): left to the allocator, the updated vector got new registers and the COMMON path paid
+            // 8 v_mov_b64 per half tile plus 16 v_mov at the loop's back edge to carry it
+            const float nm = -m;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -m;
+            for (int r = 0; r < 16; ++r) asm volatile("v_mov_b32 %0, %1" : "+v"(negm[r]) : "v"(nm));
+        }
         if (fix_c1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) c1[r] -= delta;             // (-inf stays -inf)
