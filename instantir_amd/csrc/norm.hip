@@ -101,43 +101,58 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* Xp, long ldx, 
 }
 
 // ---- GroupNorm pass 2: merge the slab partials to mean / rstd per (image, group) ------------------
-// One WAVE per (image, group): lane l takes slabs l, l + 64, ... (independent loads, issued before any merge), then the 64
-// lane results are merged by a fixed butterfly -- reproducible, and no serial chain of dependent global loads (the first
-// form, one 256-thread workgroup per image walking 32 slabs per thread, took 11 us per launch, 113 launches per step).
+// One workgroup per (image, 8 groups): thread = (group g8 of 8, slab lane sl of 32); every lane issues ALL its loads (slabs
+// sl, sl + 32, ...: at most 8) before the first merge, merges them in order, and the 32 lane results of a group go through a
+// fixed two-level tree in LDS -- reproducible, no serial chain of dependent global loads (the first form, one 256-thread
+// workgroup per image walking 32 slabs per thread with a load -> merge -> load chain, took 11 us per launch, 113 per step).
+// (An intermediate form, one wave per (image, group) with a `__shfl_xor` butterfly, produced run-to-run different statistics
+//  whenever a conv kernel of the other stream shared the chip -- `tools/racecheck_concurrent.py`; not root-caused, replaced.)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int nslab, int G, int HW, int pix_per_slab, int cpg,
-                                                          float eps, float* stat /*[R][G][2]*/, int RG) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (w >= RG) return;
-    const int r = w / G, gi = w - r * G;
-    const float* base = part + ((long)r * nslab * G + gi) * 2;
-    constexpr int MAXS = 4;                        // nslab <= 256
-    float2 a[MAXS];
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-        const int sl = lane + k * 64;
-        a[k] = sl < nslab ? *(const float2*)(base + (long)sl * G * 2) : make_float2(0.f, 0.f);
-    }
+                                                          float eps, float* stat /*[R][G][2]*/, int gblocks) {
+    __shared__ float sn[256], smean[256], sm2[256];
+    const int r = blockIdx.x / gblocks, gb = blockIdx.x - r * gblocks;
+    const int g8 = threadIdx.x & 7, sl = threadIdx.x >> 3;       // 8 groups x 32 slab lanes
+    const int gi = gb * 8 + g8;
+    constexpr int MAXS = 8;                                      // nslab <= 256
     float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (gi < G) {
+        const float* base = part + ((long)r * nslab * G + gi) * 2;
+        float2 a[MAXS];
 #pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-        const int sl = lane + k * 64;
-        if (sl < nslab) {
-            const int p0 = sl * pix_per_slab, p1 = min(HW, p0 + pix_per_slab);
-            chan_merge(n, mean, m2, (float)(p1 - p0) * (float)cpg, a[k].x, a[k].y);
+        for (int k = 0; k < MAXS; ++k) {
+            const int s_ = min(sl + k * 32, nslab - 1);          // clamped: unconditional loads, one batch
+            a[k] = *(const float2*)(base + (long)s_ * G * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) {
+            const int s_ = sl + k * 32;
+            if (s_ < nslab) {
+                const int p0 = s_ * pix_per_slab, p1 = min(HW, p0 + pix_per_slab);
+                chan_merge(n, mean, m2, (float)(p1 - p0) * (float)cpg, a[k].x, a[k].y);
+            }
         }
     }
+    sn[threadIdx.x] = n; smean[threadIdx.x] = mean; sm2[threadIdx.x] = m2;
+    __syncthreads();
+    if (threadIdx.x < 64) {                                      // level 1: (group g8, segment seg of 8) merges 4 slab lanes
+        const int seg = threadIdx.x >> 3;
+        float tn = 0.f, tm = 0.f, tq = 0.f;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {             // butterfly: both partners compute the same merge in the same operand order
-        const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
-        const bool lo = (lane & o) == 0;
-        float n0 = lo ? n : nb, me0 = lo ? mean : mb, q0 = lo ? m2 : qb;          // lower lane's value first
-        const float n1 = lo ? nb : n, me1 = lo ? mb : mean, q1 = lo ? qb : m2;
-        chan_merge(n0, me0, q0, n1, me1, q1);
-        n = n0; mean = me0; m2 = q0;
+        for (int l = 0; l < 4; ++l) {
+            const int src = (seg * 4 + l) * 8 + g8;
+            chan_merge(tn, tm, tq, sn[src], smean[src], sm2[src]);
+        }
+        n = tn; mean = tm; m2 = tq;
     }
-    if (lane == 0) {
-        stat[((long)r * G + gi) * 2] = mean;
-        stat[((long)r * G + gi) * 2 + 1] = rsqrtf(m2 / n + eps);
+    __syncthreads();
+    if (threadIdx.x < 64) { sn[threadIdx.x] = n; smean[threadIdx.x] = mean; sm2[threadIdx.x] = m2; }
+    __syncthreads();
+    if (threadIdx.x < 8 && gi < G) {                             // level 2: the 8 segments of a group
+        float tn = 0.f, tm = 0.f, tq = 0.f;
+#pragma unroll
+        for (int sgm = 0; sgm < 8; ++sgm) chan_merge(tn, tm, tq, sn[sgm * 8 + g8], smean[sgm * 8 + g8], sm2[sgm * 8 + g8]);
+        stat[((long)r * G + gi) * 2] = tm;
+        stat[((long)r * G + gi) * 2 + 1] = rsqrtf(tq / tn + eps);
     }
 }
 
@@ -415,7 +430,8 @@ extern "C" int iir_groupnorm_nhwc(const void* X, int64_t ldx, void* Y, int64_t l
     nblk = (HW + ppb - 1) / ppb;
     if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(nslab, R), dim3(256), 0, st, (const f16*)X, (long)ldx, HW, C, groups, pps, part);
     else hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(nslab, R), dim3(256), 0, st, (const f16*)X, (long)ldx, HW, C, groups, pps, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((R * groups + 3) / 4), dim3(256), 0, st, (const float*)part, nslab, groups, HW, pps, C / groups, eps, stat, R * groups);
+    const int gblocks = (groups + 7) / 8;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(R * gblocks), dim3(256), 0, st, (const float*)part, nslab, groups, HW, pps, C / groups, eps, stat, gblocks);
     if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(nblk, R), dim3(256), 0, st, (const f16*)X, (long)ldx, (f16*)Y, (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
     else hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(nblk, R), dim3(256), 0, st, (const f16*)X, (long)ldx, (f16*)Y, (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
     return iir_launch_status();

@@ -504,3 +504,31 @@ def test_gemm_layernorm_fold(dev, M, C, N, geglu):
     _close(out, want, rtol=tol, atol=tol, what="LayerNorm-folded gemm")
     with pytest.raises(ValueError):
         ops.gemm(h, fold.w, out, bias=fold.bias, epi=ops.EPI_GEGLU if geglu else ops.EPI_PLAIN, ln_in=(stats[:, :M // 2], fold.colsum, fold.eps))
+
+
+def test_groupnorm_reproducible_beside_a_conv(dev):
+    """Regression: GroupNorm must give bit-identical results when another stream keeps the chip busy (the step runs the main
+    UNet's encoder beside the previewer UNet + Aggregator).  A wave-butterfly form of the finalize kernel produced run-to-run
+    different statistics exactly then -- only beside conv kernels, never alone -- which made the whole pipeline irreproducible
+    (found by `tools/racecheck_concurrent.py`)."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(1)
+    side = torch.cuda.Stream()
+    cx, cw = _rand(g, 2, 64, 64, 640).to(dev), _rand(g, 640, 3, 3, 640, scale=0.02).to(dev)
+    co = torch.empty(2 * 64 * 64, 640, dtype=torch.half, device=dev)
+    for R, HW, C in ((2, 4096, 640), (2, 16384, 320), (2, 1024, 1280)):
+        x, gm, bt = _rand(g, R * HW, C).to(dev), (_rand(g, C) + 1).to(dev), _rand(g, C).to(dev)
+        ws = ops.gn_workspace(dev, R, 32)
+        first = None
+        for it in range(16):
+            ws.fill_(float(it))                          # stale workspace contents must never show
+            out = torch.zeros(R * HW, C, dtype=torch.half, device=dev)
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    ops.conv2d(cx, cw, co)
+            ops.groupnorm(x, out, R, HW, gm, bt, 1e-5, True, 32, ws)
+            torch.cuda.synchronize()
+            if first is None:
+                first = out
+            else:
+                assert torch.equal(out, first), (R, HW, C, it)

@@ -1,0 +1,96 @@
+"""Race screen UNDER CONCURRENCY: each kernel is launched REP times on one stream while a second stream keeps the chip busy with
+other kernels (the step runs two streams: main UNet encoder beside previewer UNet + Aggregator).  Every kernel is deterministic,
+so the REP outputs must be bit-identical; a kernel whose result depends on timing (a missing wait / barrier) shows up here even if
+it is reproducible when it runs alone."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from instantir_amd import ops
+from instantir_amd.packing import pair_rows, conv_weight_nhwc
+dev = torch.device("cuda:0")
+REP = int(os.environ.get("REP", "24"))
+NOISE = os.environ.get("NOISE", "1") != "0"
+g = torch.Generator().manual_seed(1)
+rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).half().to(dev)
+side = torch.cuda.Stream()
+# noise: a mix of the step's kernels
+nx, nw, no = rnd(4096, 1280), rnd(2560, 1280, scale=0.03), torch.empty(4096, 2560, dtype=torch.half, device=dev)
+nq, nvt, nao = rnd(2 * 2048, 2 * 640), rnd(640, 2 * 2048), torch.empty(2 * 2048, 640, dtype=torch.half, device=dev)
+ncx, ncw, nco = rnd(2, 64, 64, 640), rnd(640, 3, 3, 640, scale=0.02), torch.empty(2 * 64 * 64, 640, dtype=torch.half, device=dev)
+def noise(n):
+    with torch.cuda.stream(side):
+        for _ in range(n):
+            ops.gemm(nx, nw, no)
+            ops.attention(nq[:, :640], nao, [(nq[:, 640:], 2048, nvt, 2048, 2048)], 2, 10, 2048)
+            ops.conv2d(ncx, ncw, nco)
+bad = []
+def screen(name, launch, shapes, dtype=torch.half):
+    first = None; nd = 0; where = None
+    for it in range(REP):
+        outs = [torch.zeros(s, dtype=dtype, device=dev) for s in shapes]
+        if NOISE: noise(3)
+        launch(*outs)
+        torch.cuda.synchronize()
+        cat = torch.cat([o.flatten().float() for o in outs])
+        if first is None: first = cat
+        elif not torch.equal(cat, first):
+            nd += 1
+            idx = (cat != first).nonzero().flatten()
+            where = (int(idx.numel()), idx[:4].tolist(), float((cat - first).abs().max()))
+    if nd: bad.append(name)
+    print(f"{name:60s} nondeterministic_runs={nd}/{REP - 1} {where or ''}", flush=True)
+
+for (M, N, K) in [(2048, 1280, 1280), (8192, 640, 640), (2048, 1280, 5120), (2048, 3840, 1280)]:
+    x, w, b, res = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N), rnd(M, N)
+    for tile in (0, 21, 22, 24, 25, 35, 55):
+        screen(f"gemm {M}x{N}x{K} tile {tile} bias+res", lambda o: ops.gemm(x, w, o, bias=b, res=res, tile=tile), [(M, N)])
+M, N, K = 2048, 10240, 1280
+x, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+wp, bp = pair_rows(w[:N // 2], w[N // 2:]), pair_rows(b[:N // 2], b[N // 2:])
+screen("gemm GEGLU 2048x10240x1280", lambda o: ops.gemm(x, wp, o, bias=bp, epi=ops.EPI_GEGLU), [(M, N // 2)])
+C = 1280
+w3 = rnd(3 * C, C, scale=C ** -0.5)
+screen("gemm q|k|v 2048x3840x1280 (V transposed)", lambda qk, vt: ops.gemm(x, w3, qk, out_t=(vt, 2 * C)), [(M, 2 * C), (C, M)])
+# LayerNorm fold: producer partials, consumer
+parts = ops.ln_parts(M, C, C)
+h0, wo = rnd(M, C), rnd(C, C, scale=C ** -0.5)
+st = torch.zeros(parts, M, 2, device=dev)
+hh = torch.empty(M, C, dtype=torch.half, device=dev)
+def prod(o, s):
+    ops.gemm(x, wo, o, res=h0, ln_out=st); s.copy_(st)
+screen("gemm producer with ln_out (output + partials)", prod, [(M, C)], ) if False else None
+for it in range(1):
+    outs = []
+    first = None; nd = 0
+    for r_ in range(REP):
+        st.zero_(); 
+        if NOISE: noise(3)
+        ops.gemm(x, wo, hh, res=h0, ln_out=st); torch.cuda.synchronize()
+        cat = torch.cat([hh.flatten().float(), st.flatten()])
+        if first is None: first = cat
+        elif not torch.equal(cat, first): nd += 1
+    if nd: bad.append("ln producer")
+    print(f"{'gemm producer with ln_out (output + partials)':60s} nondeterministic_runs={nd}/{REP - 1}", flush=True)
+gam, bet = rnd(C) + 1, rnd(C)
+f = ops.LnFold(w3, gam, bet)
+screen("gemm consumer with ln_in (q|k|v)", lambda qk, vt: ops.gemm(hh, f.w, qk, bias=f.bias, out_t=(vt, 2 * C), ln_in=(st, f.colsum, 1e-5)), [(M, 2 * C), (C, M)])
+f1 = ops.LnFold(w, gam, bet, bias=b, pair=pair_rows)
+screen("gemm consumer with ln_in (GEGLU)", lambda o: ops.gemm(hh, f1.w, o, bias=f1.bias, epi=ops.EPI_GEGLU, ln_in=(st, f1.colsum, 1e-5)), [(M, N // 2)])
+for (R, H, Cin, Cout) in [(2, 32, 1280, 1280), (2, 64, 640, 640), (2, 128, 320, 320), (2, 32, 2560, 1280)]:
+    cx, cw, cb = rnd(R, H, H, Cin), rnd(Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5), rnd(Cout)
+    for tile in (0,):
+        screen(f"conv3x3 {R}x{H}x{H} {Cin}->{Cout} tile {tile}", lambda o: ops.conv2d(cx, cw, o, bias=cb, tile=tile), [(R * H * H, Cout)])
+for (B, heads, T, kvs) in [(2, 20, 1024, [1024]), (2, 10, 4096, [4096]), (2, 20, 1024, [77, 64]), (2, 10, 4096, [77, 64]), (2, 10, 8192, [8192])]:
+    Cc = heads * 64
+    q = rnd(B * T, Cc); segs = []
+    for Tk in kvs:
+        pad = (Tk + 7) // 8 * 8
+        segs.append((rnd(B * Tk, Cc), Tk, rnd(Cc, B * pad), pad, Tk))
+    screen(f"attention B={B} h={heads} T={T} kv={kvs}", lambda o: ops.attention(q, o, segs, B, heads, T), [(B * T, Cc)])
+for (R, HW, Cg) in [(2, 1024, 1280), (2, 4096, 640), (2, 16384, 320), (2, 1024, 2560)]:
+    gx, gg, gb = rnd(R * HW, Cg), rnd(Cg) + 1, rnd(Cg)
+    ws = ops.gn_workspace(dev, R, 32)
+    screen(f"groupnorm R={R} HW={HW} C={Cg}", lambda o: ops.groupnorm(gx, o, R, HW, gg, gb, 1e-5, True, 32, ws), [(R * HW, Cg)])
+lx, lg, lb = rnd(2048, 1280), rnd(1280) + 1, rnd(1280)
+screen("layernorm 2048x1280", lambda o: ops.layernorm(lx, o, lg, lb, 1e-5), [(2048, 1280)])
+print("kernels with run-to-run differences:", bad)
