@@ -91,6 +91,21 @@ for (R, HW, Cg) in [(2, 1024, 1280), (2, 4096, 640), (2, 16384, 320), (2, 1024, 
     gx, gg, gb = rnd(R * HW, Cg), rnd(Cg) + 1, rnd(Cg)
     ws = ops.gn_workspace(dev, R, 32)
     screen(f"groupnorm R={R} HW={HW} C={Cg}", lambda o: ops.groupnorm(gx, o, R, HW, gg, gb, 1e-5, True, 32, ws), [(R * HW, Cg)])
+# conv variants: stride 2, nearest-2x upsample folded, 1x1, SFT pair epilogue, loader-wave tile
+cx, cw, cb = rnd(2, 64, 64, 640), rnd(640, 3, 3, 640, scale=0.02), rnd(640)
+screen("conv3x3 stride 2 2x64x64 640->640", lambda o: ops.conv2d(cx, cw, o, bias=cb, stride=2), [(2 * 32 * 32, 640)])
+screen("conv3x3 upsample 2x 2x64x64 640->640", lambda o: ops.conv2d(cx, cw, o, bias=cb, upsample=True), [(2 * 128 * 128, 640)])
+c1w = rnd(1280, 1, 1, 640, scale=0.04)
+screen("conv1x1 2x64x64 640->1280", lambda o: ops.conv2d(cx, c1w, o, ksize=1), [(2 * 64 * 64, 1280)])
+sx, sw, sb, sres = rnd(2, 32, 32, 256), pair_rows(rnd(1280, 3, 3, 256, scale=0.02), rnd(1280, 3, 3, 256, scale=0.02)), pair_rows(rnd(1280), rnd(1280)), rnd(2 * 32 * 32, 1280)
+screen("conv3x3 SFT epilogue 2x32x32 256->2x1280", lambda o: ops.conv2d(sx, sw, o, bias=sb, res=sres, epi=ops.EPI_SFT), [(2 * 32 * 32, 1280)])
+l2x, l2w = rnd(2, 32, 32, 1280), rnd(1280, 3, 3, 1280, scale=0.01)
+screen("conv3x3 2x32x32 1280->1280 tile 55 (loader waves)", lambda o: ops.conv2d(l2x, l2w, o, tile=55), [(2 * 32 * 32, 1280)])
+# pointwise / glue
+ca, cadd, csc = rnd(8192, 640), rnd(8192, 640), torch.tensor([0.7, 1.0], device=dev)
+screen("copy_add 8192x640 -> cat buffer", lambda o: ops.copy_add(ca, o, 640, add=cadd, add_scale=csc, rows_per_scale=4096), [(8192, 1280)])
+sil = rnd(2, 1280)
+screen("silu", lambda o: ops.silu(sil, o), [(2, 1280)])
 lx, lg, lb = rnd(2048, 1280), rnd(1280) + 1, rnd(1280)
 screen("layernorm 2048x1280", lambda o: ops.layernorm(lx, o, lg, lb, 1e-5), [(2048, 1280)])
 print("kernels with run-to-run differences:", bad)
