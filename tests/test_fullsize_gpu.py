@@ -121,3 +121,32 @@ def test_config3_2048px_end_to_end():
     assert len(row) == 2                                   # the gate closes when (i + 1) / 4 > 0.7 (:1447-1450): steps 0, 1 preview, steps 2, 3 run without previewer / Aggregator
     img2, _ = pipe(**kw)
     assert torch.equal(img, img2)                          # bit-reproducible run to run (no atomics anywhere on the path)
+
+
+def test_two_stream_step_is_bit_reproducible_1024px():
+    """The default mode (hipGraph replay, main UNet encoder on a side stream beside previewer UNet + Aggregator) must give
+    bit-identical latents run to run at configs[1]'s geometry: nothing on the path uses atomics or an order-dependent reduction.
+    (Regression for DESIGN.md section 5.8: one kernel that was only wrong beside a concurrent conv made this fail by 0.4 %.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from instantir_amd import lib, weights as W
+    from instantir_amd.config import UNetConfig
+    from instantir_amd.pipeline import InstantIRPipeline
+    from instantir_amd.schedulers import DDIMScheduler, LCMSingleStepScheduler
+    lib.load()
+    dev = torch.device("cuda:0")
+    cfg = UNetConfig.sdxl()
+    pipe = InstantIRPipeline(cfg, W.synth_state_dict(W.unet_specs(cfg), 1234, device=dev), scheduler=DDIMScheduler(), device=dev)
+    pipe.aggregator.load_state_dict(W.synth_state_dict(W.aggregator_specs(cfg), 1235, device=dev))
+    pipe.prepare_previewers(W.synth_state_dict(W.lora_specs(cfg), 1236, device=dev), lora_alpha=8)
+    g = torch.Generator().manual_seed(42)
+    kw = dict(image=torch.randn(1, 4, 128, 128, generator=g) * 0.8, prompt_embeds=torch.randn(1, 77, 2048, generator=g),
+              pooled_prompt_embeds=torch.randn(1, 1280, generator=g), negative_prompt_embeds=torch.randn(1, 77, 2048, generator=g),
+              negative_pooled_prompt_embeds=torch.randn(1, 1280, generator=g), ip_adapter_image_embeds=[torch.randn(2, 1, 257, 1024, generator=g)],
+              output_type="latent", num_inference_steps=3, guidance_scale=7.0, init_noise=torch.randn(1, 4, 128, 128, generator=g),
+              previewer_scheduler=LCMSingleStepScheduler.from_config(pipe.scheduler.config))
+    assert pipe.use_graphs and pipe.overlap_streams
+    outs = [pipe(**kw).images.float().cpu() for _ in range(3)]
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    pipe.use_graphs = pipe.overlap_streams = False
+    assert torch.equal(pipe(**kw).images.float().cpu(), outs[0])          # and the single-stream eager path gives the same bits
