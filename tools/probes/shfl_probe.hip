@@ -6,6 +6,7 @@
 //   V2  butterfly through LDS instead of ds_bpermute, Chan merge with the early return
 //   V3  V0 with unconditional (clamped) loads instead of one predicated load per basic block
 //   V4  V0 with an explicit `s_waitcnt vmcnt(0)` behind the predicated loads
+//   V5  V0 with the four load-address register pairs kept live to the end of the kernel (the allocator cannot reuse them)
 //   hipcc --offload-arch=gfx950 -O3 -I include tools/probes/shfl_probe.hip -o tools/probes/bin/shfl_probe -ldl
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -37,11 +38,13 @@ __global__ __launch_bounds__(256) void fin(const float* part, int nslab, int G, 
     const int r = w / G, gi = w - r * G;
     const float* base = part + ((long)r * nslab * G + gi) * 2;
     float2 a[4];
+    const float2* ptr[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int sl = lane + k * 64;
+        ptr[k] = (const float2*)(base + (long)sl * G * 2);
         if (V == 3) a[k] = *(const float2*)(base + (long)min(sl, nslab - 1) * G * 2);          // unconditional, clamped
-        else a[k] = sl < nslab ? *(const float2*)(base + (long)sl * G * 2) : make_float2(0.f, 0.f);
+        else a[k] = sl < nslab ? *ptr[k] : make_float2(0.f, 0.f);
     }
     if (V == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // explicit wait behind the predicated loads
     float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -62,6 +65,11 @@ __global__ __launch_bounds__(256) void fin(const float* part, int nslab, int G, 
         const float n1 = lo ? nb : n, me1 = lo ? mb : mean, q1 = lo ? qb : m2;
         if (V == 1) merge_nobr(n0, me0, q0, n1, me1, q1); else merge_ret(n0, me0, q0, n1, me1, q1);
         n = n0; mean = me0; m2 = q0;
+    }
+    if (V == 5 && n == -12345.f) {     // never true: keeps the four address register pairs alive to the end of the kernel
+        unsigned long acc = 0;
+        for (int k = 0; k < 4; ++k) acc += (unsigned long)ptr[k];
+        stat[0] = (float)acc;
     }
     if (lane == 0) { stat[((long)r * G + gi) * 2] = mean; stat[((long)r * G + gi) * 2 + 1] = rsqrtf(m2 / n + 1e-5f); }
 }
@@ -96,7 +104,7 @@ int main(int argc, char** argv) {
     struct Nz { const char* name; int kind, tile; } nzs[] = {{"none", 0, 0}, {"gemm 128x128", 1, 21}, {"gemm 128x160", 1, 24}, {"gemm 64x160", 1, 25}, {"gemm 64x64", 1, 23},
                                                              {"conv 128x160", 2, 24}, {"conv 64x160", 2, 25}};
     for (auto& z : nzs)
-        for (int v = 0; v < 5; ++v) {
+        for (int v = 0; v < 6; ++v) {
             int nd = 0; float maxd = 0.f;
             for (int it = 0; it < REP; ++it) {
                 for (int k = 0; k < 3; ++k) {
@@ -110,6 +118,7 @@ int main(int argc, char** argv) {
                 if (v == 2) hipLaunchKernelGGL(fin<2>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 if (v == 3) hipLaunchKernelGGL(fin<3>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 if (v == 4) hipLaunchKernelGGL(fin<4>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
+                if (v == 5) hipLaunchKernelGGL(fin<5>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 CK(hipDeviceSynchronize());
                 CK(hipMemcpy(cur.data(), stat, RG * 2 * 4, hipMemcpyDeviceToHost));
                 if (it == 0) first = cur;
