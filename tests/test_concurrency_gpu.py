@@ -1,6 +1,6 @@
 """Every kernel must give bit-identical results when a second stream keeps the chip busy: the step runs the main UNet's encoder
 beside the previewer UNet + Aggregator, and a kernel that is only reproducible when it has the chip to itself makes the whole
-pipeline irreproducible.  The full screen is `tools/racecheck_concurrent.py` (54 cases); this is the
+pipeline irreproducible.  The full screen is `tools/racecheck_concurrent.py` (60 cases); this is the
 driver-run subset: one case per kernel family, 8 launches each, beside GEMM + attention + 64-row-tile conv noise."""
 import pytest
 import torch

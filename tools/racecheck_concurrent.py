@@ -106,6 +106,24 @@ ca, cadd, csc = rnd(8192, 640), rnd(8192, 640), torch.tensor([0.7, 1.0], device=
 screen("copy_add 8192x640 -> cat buffer", lambda o: ops.copy_add(ca, o, 640, add=cadd, add_scale=csc, rows_per_scale=4096), [(8192, 1280)])
 sil = rnd(2, 1280)
 screen("silu", lambda o: ops.silu(sil, o), [(2, 1280)])
+# the small launches of a step (few workgroups: the occupancy of the finalize kernel that failed)
+xl = (torch.randn(1, 4, 128, 128, generator=g) * 0.8).to(dev)
+screen("pack_latent (rep 2)", lambda o: ops.pack_latent(xl, o, rep=2), [(2 * 128 * 128, 64)])
+eps2 = rnd(2 * 128 * 128, 64)
+coef = torch.tensor([7.0, 0.9, 0.3, 0.8, 0.5, 0.0, 0.0, 0.0], device=dev)
+screen("sched_step (CFG + DDIM)", lambda o: ops.sched_step(eps2, 1, coef, xl, o), [(1, 4, 128, 128)], dtype=torch.float32)
+lcoef = torch.tensor([0.1, 0.9, 0.3, 0.95], device=dev)
+screen("lcm_step", lambda o, p32: ops.lcm_step(eps2, 1, 2, lcoef, xl, o, p32), [(2 * 128 * 128, 64), (2, 4, 128, 128)]) if False else None
+tv = torch.tensor([[499.0], [499.0]], device=dev)
+screen("sinusoid", lambda o: ops.sinusoid(tv, o, 320), [(2, 320)])
+e1, tw, tb_ = rnd(2, 1280), rnd(1280, 320, scale=0.05), rnd(1280)
+sn_ = rnd(2, 320)
+screen("gemm M=2 (time embedding)", lambda o: ops.gemm(sn_, tw, o, bias=tb_, act=ops.ACT_SILU), [(2, 1280)])
+lnx, lng, lnb = rnd(2 * 64, 2048), rnd(2048) + 1, rnd(2048)
+screen("layernorm 128x2048 (ip tokens)", lambda o: ops.layernorm(lnx, o, lng, lnb, 1e-6), [(128, 2048)])
+gsm, gsg, gsb = rnd(2 * 64, 1280), rnd(1280) + 1, rnd(1280)
+wsm = ops.gn_workspace(dev, 2, 32)
+screen("groupnorm R=2 HW=64 C=1280 (8x8 map)", lambda o: ops.groupnorm(gsm, o, 2, 64, gsg, gsb, 1e-5, True, 32, wsm), [(128, 1280)])
 lx, lg, lb = rnd(2048, 1280), rnd(1280) + 1, rnd(1280)
 screen("layernorm 2048x1280", lambda o: ops.layernorm(lx, o, lg, lb, 1e-5), [(2048, 1280)])
 print("kernels with run-to-run differences:", bad)
