@@ -74,6 +74,21 @@ __global__ __launch_bounds__(256) void fin(const float* part, int nslab, int G, 
     if (lane == 0) { stat[((long)r * G + gi) * 2] = mean; stat[((long)r * G + gi) * 2 + 1] = rsqrtf(m2 / n + 1e-5f); }
 }
 
+// neutral noise: no LDS, no LDS-DMA, no MFMA -- VGPRS live values keep the register footprint at ~VGPRS
+template <int VGPRS>
+__global__ __launch_bounds__(256) void spin(float* out, int iters) {
+    float v[VGPRS];
+#pragma unroll
+    for (int i = 0; i < VGPRS; ++i) v[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int i = 0; i < VGPRS; ++i) v[i] = fmaf(v[i], 1.0001f, 0.5f);
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < VGPRS; ++i) r += v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -94,15 +109,20 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&cx, 2L * 64 * 64 * 640 * 2)); CK(hipMalloc(&cw, 640L * 9 * 640 * 2)); CK(hipMalloc(&cy, 2L * 64 * 64 * 640 * 2)); CK(hipMalloc(&zp, 4096));
     CK(hipMalloc(&ga, 4096L * 1280 * 2)); CK(hipMalloc(&gw, 2560L * 1280 * 2)); CK(hipMalloc(&gc, 4096L * 2560 * 2));
     CK(hipMemset(cx, 0, 2L * 64 * 64 * 640 * 2)); CK(hipMemset(cw, 0, 640L * 9 * 640 * 2)); CK(hipMemset(zp, 0, 4096)); CK(hipMemset(ga, 0, 4096L * 1280 * 2)); CK(hipMemset(gw, 0, 2560L * 1280 * 2));
-    hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipStream_t sa, sb;
+    const bool prio = getenv("PROBE_PRIO") != nullptr;       // reduction stream at the highest priority, noise at the lowest
+    int plo = 0, phi = 0; CK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+    if (prio) { CK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, phi)); CK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, plo)); }
+    else { CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)); }
+    float* spin_out; CK(hipMalloc(&spin_out, 1024 * 256 * 4));
     iir_conv_desc cd; memset(&cd, 0, sizeof cd);
     cd.X = cx; cd.ldx = 640; cd.R = 2; cd.H = 64; cd.Wd = 64; cd.Cin = 640; cd.Wt = cw; cd.Y = cy; cd.ldy = 640; cd.Cout = 640; cd.ksize = 3; cd.stride = 1; cd.zero_page = zp;
     iir_gemm_desc gd; memset(&gd, 0, sizeof gd);
     gd.A = ga; gd.lda = 1280; gd.W = gw; gd.C = gc; gd.ldc = 2560; gd.M = 4096; gd.N = 2560; gd.K = 1280;
     std::vector<float> first(RG * 2), cur(RG * 2);
     // noise = (kind, tile): which kernel of the library keeps the other stream busy
-    struct Nz { const char* name; int kind, tile; } nzs[] = {{"none", 0, 0}, {"gemm 128x128", 1, 21}, {"gemm 128x160", 1, 24}, {"gemm 64x160", 1, 25}, {"gemm 64x64", 1, 23},
-                                                             {"conv 128x160", 2, 24}, {"conv 64x160", 2, 25}};
+    struct Nz { const char* name; int kind, tile; } nzs[] = {{"none", 0, 0}, {"gemm 128x160", 1, 24}, {"gemm 64x160", 1, 25},
+                                                             {"spin 32 vgpr", 4, 32}, {"spin 96 vgpr", 4, 96}, {"spin 160 vgpr", 4, 160}};
     for (auto& z : nzs)
         for (int v = 0; v < 6; ++v) {
             int nd = 0; float maxd = 0.f;
@@ -110,7 +130,10 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 3; ++k) {
                     gd.tile = z.tile; cd.tile = z.tile; cd.ksize = z.kind == 3 ? 1 : 3;
                     if (z.kind == 1 && gemm(&gd, sb)) { printf("gemm launch failed\n"); return 1; }
-                    if (z.kind >= 2 && conv(&cd, sb)) { printf("conv launch failed\n"); return 1; }
+                    if ((z.kind == 2 || z.kind == 3) && conv(&cd, sb)) { printf("conv launch failed\n"); return 1; }
+                    if (z.kind == 4 && z.tile == 32) hipLaunchKernelGGL(spin<32>, dim3(1024), dim3(256), 0, sb, spin_out, 400);
+                    if (z.kind == 4 && z.tile == 96) hipLaunchKernelGGL(spin<96>, dim3(1024), dim3(256), 0, sb, spin_out, 140);
+                    if (z.kind == 4 && z.tile == 160) hipLaunchKernelGGL(spin<160>, dim3(1024), dim3(256), 0, sb, spin_out, 80);
                 }
                 CK(hipMemsetAsync(stat, 0, RG * 2 * 4, sa));
                 if (v == 0) hipLaunchKernelGGL(fin<0>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
