@@ -6,6 +6,7 @@
 //   V2  butterfly through LDS instead of ds_bpermute, Chan merge with the early return
 //   V3  V0 with unconditional (clamped) loads instead of one predicated load per basic block
 //   V4  V0 with an explicit `s_waitcnt vmcnt(0)` behind the predicated loads
+//   V6  V0 with a sentinel (1e6) instead of 0 as the value of a lane whose predicate is false (all predicates are true here)
 //   V5  V0 with the four load-address register pairs kept live to the end of the kernel (the allocator cannot reuse them)
 //   hipcc --offload-arch=gfx950 -O3 -I include tools/probes/shfl_probe.hip -o tools/probes/bin/shfl_probe -ldl
 #include <hip/hip_runtime.h>
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void fin(const float* part, int nslab, int G, 
         const int sl = lane + k * 64;
         ptr[k] = (const float2*)(base + (long)sl * G * 2);
         if (V == 3) a[k] = *(const float2*)(base + (long)min(sl, nslab - 1) * G * 2);          // unconditional, clamped
+        else if (V == 6) a[k] = sl < nslab ? *ptr[k] : make_float2(1.0e6f, 0.f);      // sentinel: a lane that skips its load shows as a huge mean
         else a[k] = sl < nslab ? *ptr[k] : make_float2(0.f, 0.f);
     }
     if (V == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // explicit wait behind the predicated loads
@@ -89,6 +91,39 @@ __global__ __launch_bounds__(256) void spin(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+// direct check of the lane exchange: every lane knows what its partner holds, so a wrong ds_bpermute result is counted on the GPU
+__global__ __launch_bounds__(256) void bperm_check(unsigned* mismatches, int iters) {
+    const int lane = threadIdx.x & 63;
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float mine = (float)(lane * 131 + it * 7 + o), theirs = (float)((lane ^ o) * 131 + it * 7 + o);
+            const float got = __shfl_xor(mine, o, 64);
+            bad += got != theirs;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// direct check of the predicated loads: tab[i] = i, every lane knows what it must receive
+__global__ __launch_bounds__(256) void load_check(const float* tab, int n, int stride, unsigned* mismatches, int iters) {
+    const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int off = (it * 13 + w * 7) & 63;
+        float a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int sl = lane + k * 64;
+            a[k] = sl < n ? tab[(long)sl * stride + off] : -1.f;          // the same form as V0's loads: one predicated load per basic block
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bad += a[k] != (float)((lane + k * 64) * stride + off);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -123,8 +158,34 @@ int main(int argc, char** argv) {
     // noise = (kind, tile): which kernel of the library keeps the other stream busy
     struct Nz { const char* name; int kind, tile; } nzs[] = {{"none", 0, 0}, {"gemm 128x160", 1, 24}, {"gemm 64x160", 1, 25},
                                                              {"spin 32 vgpr", 4, 32}, {"spin 96 vgpr", 4, 96}, {"spin 160 vgpr", 4, 160}};
+    unsigned* mm; CK(hipMalloc(&mm, 4));
+    float* tab; { std::vector<float> ht(256 * 64 + 64); for (size_t i = 0; i < ht.size(); ++i) ht[i] = (float)i; CK(hipMalloc(&tab, ht.size() * 4)); CK(hipMemcpy(tab, ht.data(), ht.size() * 4, hipMemcpyHostToDevice)); }
+    for (auto& z : nzs) {            // the exchange on its own, 16 workgroups x 2000 iterations x 6 exchanges per launch, 20 launches
+        CK(hipMemset(mm, 0, 4));
+        for (int it = 0; it < 20; ++it) {
+            for (int k = 0; k < 3; ++k) {
+                gd.tile = z.tile;
+                if (z.kind == 1 && gemm(&gd, sb)) { printf("gemm launch failed\n"); return 1; }
+            }
+            hipLaunchKernelGGL(bperm_check, dim3(16), dim3(256), 0, sa, mm, 2000);
+            CK(hipDeviceSynchronize());
+        }
+        unsigned hm = 0; CK(hipMemcpy(&hm, mm, 4, hipMemcpyDeviceToHost));
+        if (z.kind <= 1) printf("noise %-13s ds_bpermute self-check: %u wrong exchanges of %ld\n", z.name, hm, 20L * 16 * 256 * 2000 * 6);
+        CK(hipMemset(mm, 0, 4));
+        for (int it = 0; it < 20; ++it) {
+            for (int k = 0; k < 3; ++k) {
+                gd.tile = z.tile;
+                if (z.kind == 1 && gemm(&gd, sb)) { printf("gemm launch failed\n"); return 1; }
+            }
+            hipLaunchKernelGGL(load_check, dim3(16), dim3(256), 0, sa, tab, 256, 64, mm, 2000);
+            CK(hipDeviceSynchronize());
+        }
+        CK(hipMemcpy(&hm, mm, 4, hipMemcpyDeviceToHost));
+        if (z.kind <= 1) printf("noise %-13s predicated-load self-check: %u wrong values of %ld\n", z.name, hm, 20L * 16 * 256 * 2000 * 4);
+    }
     for (auto& z : nzs)
-        for (int v = 0; v < 6; ++v) {
+        for (int v = 0; v < 7; ++v) {
             int nd = 0; float maxd = 0.f;
             for (int it = 0; it < REP; ++it) {
                 for (int k = 0; k < 3; ++k) {
@@ -142,6 +203,7 @@ int main(int argc, char** argv) {
                 if (v == 3) hipLaunchKernelGGL(fin<3>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 if (v == 4) hipLaunchKernelGGL(fin<4>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 if (v == 5) hipLaunchKernelGGL(fin<5>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
+                if (v == 6) hipLaunchKernelGGL(fin<6>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 CK(hipDeviceSynchronize());
                 CK(hipMemcpy(cur.data(), stat, RG * 2 * 4, hipMemcpyDeviceToHost));
                 if (it == 0) first = cur;
