@@ -7,6 +7,7 @@
 //   V3  V0 with unconditional (clamped) loads instead of one predicated load per basic block
 //   V4  V0 with an explicit `s_waitcnt vmcnt(0)` behind the predicated loads
 //   V6  V0 with a sentinel (1e6) instead of 0 as the value of a lane whose predicate is false (all predicates are true here)
+//   V7  V0 with v_rcp_f32 in the merges instead of the IEEE division sequence (v_div_scale / v_div_fmas / v_div_fixup)
 //   V5  V0 with the four load-address register pairs kept live to the end of the kernel (the allocator cannot reuse them)
 //   hipcc --offload-arch=gfx950 -O3 -I include tools/probes/shfl_probe.hip -o tools/probes/bin/shfl_probe -ldl
 #include <hip/hip_runtime.h>
@@ -26,6 +27,14 @@ __device__ __forceinline__ void merge_ret(float& n, float& mean, float& m2, floa
 }
 __device__ __forceinline__ void merge_nobr(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
     const float tot = n + nb, d = mb - mean, inv = 1.0f / fmaxf(tot, 1e-30f);
+    mean += d * (nb * inv);
+    m2 += m2b + d * d * (n * nb * inv);
+    n = tot;
+}
+
+__device__ __forceinline__ void merge_rcp(float& n, float& mean, float& m2, float nb, float mb, float m2b) {   // no IEEE division sequence
+    if (nb <= 0.f) return;
+    const float tot = n + nb, d = mb - mean, inv = __builtin_amdgcn_rcpf(tot);
     mean += d * (nb * inv);
     m2 += m2b + d * d * (n * nb * inv);
     n = tot;
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(256) void fin(const float* part, int nslab, int G, 
     if (V == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // explicit wait behind the predicated loads
     float n = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (lane + k * 64 < nslab) { if (V == 1) merge_nobr(n, mean, m2, cnt, a[k].x, a[k].y); else merge_ret(n, mean, m2, cnt, a[k].x, a[k].y); }
+    for (int k = 0; k < 4; ++k) if (lane + k * 64 < nslab) { if (V == 1) merge_nobr(n, mean, m2, cnt, a[k].x, a[k].y); else if (V == 7) merge_rcp(n, mean, m2, cnt, a[k].x, a[k].y); else merge_ret(n, mean, m2, cnt, a[k].x, a[k].y); }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         float nb, mb, qb;
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(256) void fin(const float* part, int nslab, int G, 
         const bool lo = (lane & o) == 0;
         float n0 = lo ? n : nb, me0 = lo ? mean : mb, q0 = lo ? m2 : qb;
         const float n1 = lo ? nb : n, me1 = lo ? mb : mean, q1 = lo ? qb : m2;
-        if (V == 1) merge_nobr(n0, me0, q0, n1, me1, q1); else merge_ret(n0, me0, q0, n1, me1, q1);
+        if (V == 1) merge_nobr(n0, me0, q0, n1, me1, q1); else if (V == 7) merge_rcp(n0, me0, q0, n1, me1, q1); else merge_ret(n0, me0, q0, n1, me1, q1);
         n = n0; mean = me0; m2 = q0;
     }
     if (V == 5 && n == -12345.f) {     // never true: keeps the four address register pairs alive to the end of the kernel
@@ -185,7 +194,7 @@ int main(int argc, char** argv) {
         if (z.kind <= 1) printf("noise %-13s predicated-load self-check: %u wrong values of %ld\n", z.name, hm, 20L * 16 * 256 * 2000 * 4);
     }
     for (auto& z : nzs)
-        for (int v = 0; v < 7; ++v) {
+        for (int v = 0; v < 8; ++v) {
             int nd = 0; float maxd = 0.f;
             for (int it = 0; it < REP; ++it) {
                 for (int k = 0; k < 3; ++k) {
@@ -204,6 +213,7 @@ int main(int argc, char** argv) {
                 if (v == 4) hipLaunchKernelGGL(fin<4>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 if (v == 5) hipLaunchKernelGGL(fin<5>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 if (v == 6) hipLaunchKernelGGL(fin<6>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
+                if (v == 7) hipLaunchKernelGGL(fin<7>, dim3((RG + 3) / 4), dim3(256), 0, sa, part, nslab, G, 320.f, stat, RG);
                 CK(hipDeviceSynchronize());
                 CK(hipMemcpy(cur.data(), stat, RG * 2 * 4, hipMemcpyDeviceToHost));
                 if (it == 0) first = cur;
