@@ -213,11 +213,15 @@ __device__ __forceinline__ void ln_row(const f16* X, long ldx, f16* Y, long ldy,
     f16x8 v[MAXK];
     float s = 0.f;
     const f16* x = X + (long)row * ldx;
+    // (unconditional, clamped loads: the form `if (ch < nchunk) v[k] = load` -- one predicated load per basic block feeding a
+    //  `__shfl_xor` reduction -- is the one that produced run-to-run different results beside a concurrent 64-row-tile GEMM in
+    //  the GroupNorm finalize kernel; this kernel never showed it, the form is avoided all the same)
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) v[k] = *(const f16x8*)(x + min(lane + k * 64, nchunk - 1) * 8);
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
         const int ch = lane + k * 64;
         if (ch < nchunk) {
-            v[k] = *(const f16x8*)(x + ch * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += (float)v[k][j];
         }
@@ -292,10 +296,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(f16* X, long ld, int 
     f16x8 v[MAXK];
     float mx = -INFINITY;
 #pragma unroll
+    for (int k = 0; k < MAXK; ++k) v[k] = *(const f16x8*)(x + min((int)threadIdx.x + k * 256, nchunk - 1) * 8);      // unconditional, clamped (see ln_row)
+#pragma unroll
     for (int k = 0; k < MAXK; ++k) {
         const int ch = threadIdx.x + k * 256;
         if (ch < nchunk) {
-            v[k] = *(const f16x8*)(x + ch * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[k][j]);
         }
