@@ -350,12 +350,11 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* S, l
     f32x4 v[MAXK];
     float mx = -INFINITY;
 #pragma unroll
+    for (int k = 0; k < MAXK; ++k) v[k] = *(const f32x4*)(x + min((int)threadIdx.x + k * 256, nchunk - 1) * 4);     // unconditional, clamped (see ln_row)
+#pragma unroll
     for (int k = 0; k < MAXK; ++k) {
         const int ch = threadIdx.x + k * 256;
-        if (ch < nchunk) {
-            v[k] = *(const f32x4*)(x + ch * 4);
-            mx = fmaxf(fmaxf(mx, fmaxf(v[k][0], v[k][1])), fmaxf(v[k][2], v[k][3]));
-        }
+        if (ch < nchunk) mx = fmaxf(fmaxf(mx, fmaxf(v[k][0], v[k][1])), fmaxf(v[k][2], v[k][3]));
     }
     mx = wave_max(mx);
     if (lane == 0) red[wv] = mx;
