@@ -437,7 +437,11 @@ __device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const 
 // alone on its CU) to land; the 320-workgroup level-2 launches and the cross-attention launches waited ~1 us per tile on them.
 // NB - 1 tiles are in flight; the wait at the end of tile t is counted (`vmcnt(4 * tiles still allowed in flight)`), 4 LDS-DMA
 // instructions per wave and tile.
-template <int WPS, int NB>
+// PRE (round 3): the whole KV of every segment fits the ring (<= NB tiles in all: the text + IP cross-attention, 77 + 64 keys
+// = 3 tiles).  Every tile of every segment is requested at kernel entry, there is ONE wait and one barrier, and the tile
+// bodies then run back to back -- the ring form paid a full load latency per segment plus a wait and a barrier per tile
+// for launches whose arithmetic is ~1 us (140 such launches per step, ~18 us each).
+template <int WPS, int NB, bool PRE = false>
 __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                    // [NB][64 keys][128 B]
@@ -475,39 +479,53 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
     f16x2 ohold[16];
     const int srow = lane >> 3, spos = lane & 7;
 
-    for (int sg = 0; sg < g.nseg; ++sg) {
-        const Seg s = g.seg[sg];
+    auto stage_seg = [&](const Seg& s, int t, int buf) {
         const f16* kbase = s.K + (long)b * s.kbs + h * 64;
         const f16* vbase = s.Vt + (long)(h * 64) * s.ldvt + (long)b * s.vbs;
-        const int ntiles = (s.Tkv + KT - 1) / KT;
         const int tpad = (s.Tkv + 7) & ~7;
-
-        auto stage = [&](int t, int buf) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r0 = (i * 4 + wave) * 8;
-                // LDS row rho holds key pi(rho) = rho with bits 2 and 3 swapped: accumulator row (r&3) + 8*(r>>2) + 4*hh of the
-                // score MFMA then is key 16*(r>>3) + 8*hh + (r&7) -- a lane's 8 scores of a k-step are 8 CONSECUTIVE keys
-                const int rho = r0 + srow;
-                int key = t * KT + ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1));
-                if (key >= s.Tkv) key = s.Tkv - 1;
-                const int kc = spos ^ srow;
-                glds16(kbase + (long)key * s.ldk + kc * 8, Ks + buf * KT * 128 + r0 * 128);
-                const int d = r0 + srow;
-                const int vc = spos ^ ((d >> 1) & 7);
-                int kcol = t * KT + vc * 8;
-                if (kcol >= tpad) kcol = 0;
-                glds16(vbase + (long)d * s.ldvt + kcol, Vs + buf * KT * 128 + r0 * 128);
-            }
-        };
+        for (int i = 0; i < 2; ++i) {
+            const int r0 = (i * 4 + wave) * 8;
+            // LDS row rho holds key pi(rho) = rho with bits 2 and 3 swapped: accumulator row (r&3) + 8*(r>>2) + 4*hh of the
+            // score MFMA then is key 16*(r>>3) + 8*hh + (r&7) -- a lane's 8 scores of a k-step are 8 CONSECUTIVE keys
+            const int rho = r0 + srow;
+            int key = t * KT + ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1));
+            if (key >= s.Tkv) key = s.Tkv - 1;
+            const int kc = spos ^ srow;
+            glds16(kbase + (long)key * s.ldk + kc * 8, Ks + buf * KT * 128 + r0 * 128);
+            const int d = r0 + srow;
+            const int vc = spos ^ ((d >> 1) & 7);
+            int kcol = t * KT + vc * 8;
+            if (kcol >= tpad) kcol = 0;
+            glds16(vbase + (long)d * s.ldvt + kcol, Vs + buf * KT * 128 + r0 * 128);
+        }
+    };
+    int pre_slot = 0;                     // PRE: ring slot of the current segment's first tile
+    if (PRE) {
+        int slot = 0;
+        for (int sg = 0; sg < g.nseg; ++sg) {
+            const int nt = (g.seg[sg].Tkv + KT - 1) / KT;
+            for (int t = 0; t < nt; ++t) stage_seg(g.seg[sg], t, slot++);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+
+    for (int sg = 0; sg < g.nseg; ++sg) {
+        const Seg s = g.seg[sg];
+        const int ntiles = (s.Tkv + KT - 1) / KT;
+
+        auto stage = [&](int t, int buf) { stage_seg(s, t, buf); };
 
         float m = 0.f, l = 0.f;
         f32x16 negm, o[2];
         const bool ragged = (s.Tkv % KT) != 0;
 
+        if (!PRE) {
 #pragma unroll
-        for (int i = 0; i < NB - 1; ++i)
-            if (i < ntiles) stage(i, i);
+            for (int i = 0; i < NB - 1; ++i)
+                if (i < ntiles) stage(i, i);
+        }
         // wait until at most `allowed` later tiles are still in flight (4 LDS-DMA instructions each), then barrier
         auto wait_tiles = [&](int allowed) {
             if (NB >= 4 && allowed >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
             else __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
         };
-        wait_tiles(min(NB - 2, ntiles - 1));
+        if (!PRE) wait_tiles(min(NB - 2, ntiles - 1));
         // C operand of a masked tile: `base` (0 on the first tile, -m afterwards) for visible keys, -inf for keys past the
         // end of the segment or (causal) after the query.  Built outside the steady-state loop: ragged tail / CLIP text only.
         auto build_mask = [&](int t, float base, f32x16& c0, f32x16& c1) {
@@ -531,9 +549,10 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
                     if (kb) c1[r] = v; else c0[r] = v;
                 }
         };
-        int buf = 0;                                            // ring slot of the current tile
-        auto begin_tile = [&](int t) { if (t + NB - 1 < ntiles) stage(t + NB - 1, buf == 0 ? NB - 1 : buf - 1); };   // (t + NB - 1) % NB
+        int buf = PRE ? pre_slot : 0;                           // ring slot of the current tile
+        auto begin_tile = [&](int t) { if (!PRE && t + NB - 1 < ntiles) stage(t + NB - 1, buf == 0 ? NB - 1 : buf - 1); };   // (t + NB - 1) % NB
         auto end_tile = [&](int t) {                            // tile t + 1 landed for every wave, everyone done with tile t
+            if (PRE) { ++buf; return; }                         // everything landed before the first tile; no slot is reused
             wait_tiles(max(0, min(NB - 2, ntiles - 2 - t)));
             buf = buf + 1 == NB ? 0 : buf + 1;
         };
@@ -543,11 +562,11 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
             begin_tile(0);
             if (mask_all || (ragged && ntiles == 1)) {
                 build_mask(0, 0.f, c0, c1);
-                attn_tile<true, true>(Ks, Vs, qf, c0, c1, negm, m, l, o, qi, hh);
+                attn_tile<true, true>(Ks + buf * KT * 128, Vs + buf * KT * 128, qf, c0, c1, negm, m, l, o, qi, hh);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-                attn_tile<true, false>(Ks, Vs, qf, c0, c0, negm, m, l, o, qi, hh);
+                attn_tile<true, false>(Ks + buf * KT * 128, Vs + buf * KT * 128, qf, c0, c0, negm, m, l, o, qi, hh);
             }
             end_tile(0);
         }
@@ -566,6 +585,7 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
             attn_tile<false, true>(Ks + buf * KT * 128, Vs + buf * KT * 128, qf, c0, c1, negm, m, l, o, qi, hh);
             end_tile(t);
         }
+        pre_slot += ntiles;
         const float ltot = l + __shfl_xor(l, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(ltot);
         // normalised output of this segment.  With two segments the first one's result waits as packed fp16 (16 registers
@@ -638,6 +658,21 @@ extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
         // (32 KB of dynamic LDS: below the 64 KB that needs hipFuncAttributeMaxDynamicSharedMemorySize)
         iir_launch(kern, grid, dim3(256), lds, (hipStream_t)stream, g);
     };
+    int total_tiles = 0;
+    for (int i = 0; i < a->nseg; ++i) total_tiles += (a->kv[i].Tkv + KT - 1) / KT;
+    static const bool pre_on = !(getenv("IIR_ATTN_PRE") && atoi(getenv("IIR_ATTN_PRE")) == 0);
+    if (version != 1 && pre_on && !g.causal && total_tiles <= 4) {
+        // short KV (text + IP cross-attention): every tile requested at entry, one wait, no ring (see attn_kernel2<.., PRE>)
+        static int attr_dev = -1;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (attr_dev != dev) {
+            if (hipFuncSetAttribute((const void*)attn_kernel2<2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * KT * 128) != hipSuccess) return IIR_ELAUNCH;
+            attr_dev = dev;
+        }
+        launch2(attn_kernel2<2, 4, true>, 4);
+        return iir_launch_status();
+    }
     if (version == 1) {
         if (g.qpre) g.c = 1.0f;
         iir_launch(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);

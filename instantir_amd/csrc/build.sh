@@ -6,7 +6,7 @@ OUT=../libinstantir_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -w"
 mkdir -p build
 pids=()
-for f in gemm_conv norm; do
+for f in gemm_conv gemm8 norm; do
   hipcc $FLAGS -c $f.hip -o build/$f.o &
   pids+=($!)
 done
@@ -18,5 +18,5 @@ pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c pointwise.hip -o build/pointwise.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm_conv.o build/attention.o build/norm.o build/pointwise.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm_conv.o build/gemm8.o build/attention.o build/norm.o build/pointwise.o
 echo "built $(realpath $OUT)"

@@ -18,11 +18,14 @@
 // the finished tile is staged through the (then idle) ring and written out in whole rows (or, for a column range,
 // transposed).  Optional: two-slice split-K with an in-launch reduction, LayerNorm of the A rows folded in.
 #include "common.h"
+#include "gemm_geo.h"
 #include "../../include/instantir_hip.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
+
+using iir::Geo;
 
 constexpr int BK = 64;   // halfs per K tile = one 128-byte LDS row
 constexpr int PF_TOUCHES = 4;   // prefetch touches per lane per launch (x 128 B x threads = up to 128-256 KiB per workgroup)
@@ -34,39 +37,6 @@ constexpr int PF_TOUCHES = 4;   // prefetch touches per lane per launch (x 128 B
 #define IIR_T2_MIN 256
 #endif
 
-struct Geo {   // per-launch constants shared by GEMM and CONV paths
-    const f16* A; long lda;
-    const f16* W;
-    f16* C; long ldc;
-    int M, N, K;
-    const f16* bias;
-    const f16* rowbias; long ldrb; int rows_per_rb;
-    const f16* res; long ldr;
-    int epi, act;
-    float out_scale;
-    // conv
-    int H, Wd, Cin, Ho, Wo, ks, stride, pad, ups;
-    const f16* zero;
-    long x_img_stride;        // elements between input images
-    int y_img_rows, res_img_rows;   // rows between images in C / res (conv mode); 0 = dense
-    int tiles_m, tiles_n;
-    int xm, rm, rn;           // XCD partition: xm x (8/xm) rectangles of rm x rn tiles
-    const char* pf; int pf_lines;   // weight prefetch: 128-byte lines to pull towards the Infinity Cache
-    int splitk;                     // 1 or 2 K slices per output tile (workgroups z = 0 / 1 of a tile share an XCD)
-    long sk_bytes;                  // host only: bytes of the caller's split-K workspace
-    float* sk_slabs; int* sk_cnt;   // split-K workspace: fp32 partial tiles [tile][z][BM*BN] and per-tile arrival counters
-    f16* Ct; long ldct; int tr_from, ct_vec;   // columns n >= tr_from are stored transposed: Ct[(n - tr_from) * ldct + m]
-    int c_vec, r_vec;               // C / res rows allow 16-byte accesses (ld % 8 == 0, base 16-byte aligned)
-    int dtype;                      // IIR_DT_F16 / IIR_DT_BF16: element type of A, W, C, bias, rowbias, res
-    int c_f32;                      // C is float (plain epilogue, out_scale only): the VAE's attention scores
-    const float* wscale;            // W8 build: W holds fp8-E4M3 bytes [N][K], wscale[n] its per-output-channel scale (fp32)
-    // LayerNorm folded into the GEMMs either side of it ("LayerNorm without a LayerNorm launch"):
-    float* ln_out;                  // producer: per (column tile, row) partial (mean, M2) of the rows it writes, [N/BN][M] float2
-    const float* ln_in;             // consumer: those partials; A holds the RAW rows, W has gamma folded in
-    int ln_parts, ln_part_cols;     //   partial count per row and the columns each one covers
-    float ln_eps;
-    const float* ln_colsum;         //   s[n] = sum_k W[n][k] (fp32): y = rstd * (x . w_n) - rstd * mean * s[n] (+ bias, which carries W . beta)
-};
 
 // Chan's pairwise update of (count, mean, M2) -- the same form norm.hip uses for GroupNorm
 __device__ __forceinline__ void ln_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
@@ -845,6 +815,12 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         return launch<128, 160, 3>(g2, conv, stream);
     }
     // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64, 4: 128x160, 5: 64x160}; t + 10*stages selects the ring depth.
+    // large-N linears whose 256 x 320 tiles fill the chip (the GEGLU projections): the 8-wave two-tile-deep kernel of
+    // gemm8.hip (142 FLOP per staged byte against 71 for two 128x160 workgroups per CU).  IIR_G8=0 switches it off (A/B).
+    static const bool g8_on = !(getenv("IIR_G8") && atoi(getenv("IIR_G8")) == 0);
+    if (tile == 0 && g8_on && !conv && g.K >= 640 && (long)(g.M / 256) * (g.N / 320) >= 192 && iir::gemm8_covers(g, 320))
+        return iir::gemm8_launch(g, 320, stream);
+    if (tile == 91 || tile == 92) return conv ? IIR_EINVAL : iir::gemm8_launch(g, tile == 91 ? 320 : 256, stream);
     if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
     if (tile < 10) {
         // ring depth: with at most one workgroup per CU nothing else hides the tile latency, and a long K loop

@@ -1,0 +1,46 @@
+// Per-launch constants shared by the GEMM / implicit-GEMM convolution kernels (gemm_conv.hip, gemm8.hip).
+#pragma once
+#include "common.h"
+
+namespace iir {
+
+struct Geo {   // per-launch constants shared by GEMM and CONV paths
+    const f16* A; long lda;
+    const f16* W;
+    f16* C; long ldc;
+    int M, N, K;
+    const f16* bias;
+    const f16* rowbias; long ldrb; int rows_per_rb;
+    const f16* res; long ldr;
+    int epi, act;
+    float out_scale;
+    // conv
+    int H, Wd, Cin, Ho, Wo, ks, stride, pad, ups;
+    const f16* zero;
+    long x_img_stride;        // elements between input images
+    int y_img_rows, res_img_rows;   // rows between images in C / res (conv mode); 0 = dense
+    int tiles_m, tiles_n;
+    int xm, rm, rn;           // XCD partition: xm x (8/xm) rectangles of rm x rn tiles
+    const char* pf; int pf_lines;   // weight prefetch: 128-byte lines to pull towards the Infinity Cache
+    int splitk;                     // 1 or 2 K slices per output tile (workgroups z = 0 / 1 of a tile share an XCD)
+    long sk_bytes;                  // host only: bytes of the caller's split-K workspace
+    float* sk_slabs; int* sk_cnt;   // split-K workspace: fp32 partial tiles [tile][z][BM*BN] and per-tile arrival counters
+    f16* Ct; long ldct; int tr_from, ct_vec;   // columns n >= tr_from are stored transposed: Ct[(n - tr_from) * ldct + m]
+    int c_vec, r_vec;               // C / res rows allow 16-byte accesses (ld % 8 == 0, base 16-byte aligned)
+    int dtype;                      // IIR_DT_F16 / IIR_DT_BF16: element type of A, W, C, bias, rowbias, res
+    int c_f32;                      // C is float (plain epilogue, out_scale only): the VAE's attention scores
+    const float* wscale;            // W8 build: W holds fp8-E4M3 bytes [N][K], wscale[n] its per-output-channel scale (fp32)
+    // LayerNorm folded into the GEMMs either side of it ("LayerNorm without a LayerNorm launch"):
+    float* ln_out;                  // producer: per (column tile, row) partial (mean, M2) of the rows it writes, [N/BN][M] float2
+    const float* ln_in;             // consumer: those partials; A holds the RAW rows, W has gamma folded in
+    int ln_parts, ln_part_cols;     //   partial count per row and the columns each one covers
+    float ln_eps;
+    const float* ln_colsum;         //   s[n] = sum_k W[n][k] (fp32): y = rstd * (x . w_n) - rstd * mean * s[n] (+ bias, which carries W . beta)
+};
+
+// gemm8.hip: 256 x BN tile, 8 waves, two-tile-deep LDS-DMA pipeline (BN = 320 or 256).  Returns IIR_EINVAL when the launch is
+// outside what that kernel covers (the caller then takes the 4-wave kernel).
+int gemm8_launch(const Geo& g, int bn, hipStream_t stream);
+bool gemm8_covers(const Geo& g, int bn);
+
+}  // namespace iir

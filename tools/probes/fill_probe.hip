@@ -1,0 +1,182 @@
+// L2 -> LDS fill-rate probe: how many bytes per second can ONE CU pull from L2-resident operand panels
+// into LDS, by staging form and wave count?  Emulates the operand traffic of the 2048 x 1280 x K projection GEMM (64 x 160
+// tile, one workgroup per CU, 256 workgroups): per K tile 64 rows of A and 160 rows of W, 128 bytes each = 28 KiB, no MFMA,
+// no fragment reads.  A 5 MB + W 3.3 MB are L2 / Infinity-Cache resident after the first pass.
+//   mode 0: LDS-DMA (global_load_lds_dwordx4), ring of ST stages, counted vmcnt + one barrier per K tile (the shipped protocol)
+//   mode 1: global_load_dwordx4 -> registers -> ds_write_b128, one tile of registers in flight, barrier per tile
+//   mode 2: LDS-DMA, no barrier: every wave streams its own pieces with a counted vmcnt throttle (raw issue / return rate)
+//   mode 3: global_load_dwordx4 -> registers, results discarded (no LDS write): the L2 -> register rate
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/bin/fill_probe tools/probes/fill_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+typedef _Float16 f16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 160, ROWS = BM + BN;   // 224 rows of 128 B per K tile = 28 pieces of 1 KiB
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MODE, int NW, int ST>
+__global__ __launch_bounds__(NW * 64) void fill_kernel(const f16* __restrict__ A, const f16* __restrict__ W, int K, int reps, float* sink, int xcd_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // tile of this workgroup: XCD x = blockIdx & 7.  xcd_rows = 1: XCD x owns row tiles [4x, 4x+4) and all 8 column tiles;
+    // xcd_rows = 0: XCD x owns column tile x and all 32 row tiles
+    const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int tm = xcd_rows ? x * 4 + (l & 3) : l;
+    const int tn = xcd_rows ? (l >> 2) : x;
+    constexpr int PIECES = ROWS / 8;                       // 28 pieces of 8 rows
+    constexpr int PPW = (PIECES + NW - 1) / NW;            // pieces per wave per tile
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const f16* src[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        int p = i * NW + wave;
+        if (p >= PIECES) p = PIECES - 1;                   // surplus waves re-fetch the last piece (keeps the counts uniform)
+        const int r = p * 8 + srow;
+        src[i] = r < BM ? A + (long)(tm * BM + r) * K + schunk * 8 : W + (long)(tn * BN + (r - BM)) * K + schunk * 8;
+    }
+    const int nk = K / 64;
+    const int total = nk * reps;
+    float acc = 0.f;
+    if constexpr (MODE == 0) {
+        auto stage = [&](int t, int buf) {
+            const int k0 = (t % nk) * 64;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                int p = i * NW + wave;
+                if (p >= PIECES) p = PIECES - 1;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src[i] + k0), (LDS_AS void*)(smem + buf * ROWS * 128 + p * 1024), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < ST - 1; ++s) stage(s, s);
+        int cur = 0;
+        for (int t = 0; t < total; ++t) {
+            wait_vm<(ST - 2) * PPW>();
+            __builtin_amdgcn_s_barrier();
+            if (t + ST - 1 < total) stage(t + ST - 1, (cur + ST - 1) % ST);
+            else stage(t, (cur + ST - 1) % ST);            // keep the in-flight count constant to the end
+            cur = cur + 1 == ST ? 0 : cur + 1;
+        }
+        wait_vm<0>();
+    } else if constexpr (MODE == 2) {
+        for (int t = 0; t < total; ++t) {
+            const int k0 = (t % nk) * 64, buf = t % ST;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                int p = i * NW + wave;
+                if (p >= PIECES) p = PIECES - 1;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src[i] + k0), (LDS_AS void*)(smem + buf * ROWS * 128 + p * 1024), 16, 0, 0);
+            }
+            wait_vm<(ST - 1) * PPW>();
+        }
+        wait_vm<0>();
+    } else if constexpr (MODE == 1) {
+        f32x4 r0[PPW], r1[PPW];
+        auto ld = [&](int t, f32x4 (&r)[PPW]) {
+            const int k0 = (t % nk) * 64;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) r[i] = *(const f32x4*)(src[i] + k0);
+        };
+        auto st = [&](int buf, const f32x4 (&r)[PPW]) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                int p = i * NW + wave;
+                if (p >= PIECES) p = PIECES - 1;
+                *(f32x4*)(smem + buf * ROWS * 128 + p * 1024 + lane * 16) = r[i];
+            }
+        };
+        ld(0, r0);
+        for (int t = 0; t < total; t += 2) {
+            ld(t + 1, r1);
+            st(0, r0);
+            __syncthreads();
+            ld(t + 2, r0);
+            st(1, r1);
+            __syncthreads();
+        }
+        acc += r0[0][0];
+    } else {
+        f32x4 r0[PPW], r1[PPW];
+        auto ld = [&](int t, f32x4 (&r)[PPW]) {
+            const int k0 = (t % nk) * 64;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) r[i] = *(const f32x4*)(src[i] + k0);
+        };
+        ld(0, r0);
+        for (int t = 0; t < total; t += 2) {
+            ld(t + 1, r1);
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) acc += r0[i][0] + r0[i][3];
+            ld(t + 2, r0);
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) acc += r1[i][0] + r1[i][3];
+        }
+    }
+    __syncthreads();
+    acc += ((const float*)smem)[tid];
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+template <int MODE, int NW, int ST>
+void run(const char* name, const f16* A, const f16* W, int K, float* sink, int xcd_rows, int grid) {
+    const int reps = 40;
+    const size_t lds = (MODE == 1 ? 2 : ST) * ROWS * 128 > 90 * 1024 ? (size_t)ST * ROWS * 128 : 90 * 1024;   // >= 90 KiB: one workgroup per CU
+    auto k = fill_kernel<MODE, NW, ST>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, 0, A, W, K, reps, sink, xcd_rows);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, 0, A, W, K, reps, sink, xcd_rows);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tiles = (double)(K / 64) * reps;
+    const double us_tile = ms * 1e3 / iters / tiles;
+    printf("%-34s grid %3d xcd_%s  %6.3f us per 28-KiB K tile  = %6.1f GB/s per CU, %5.2f TB/s chip\n", name, grid, xcd_rows ? "rows" : "cols", us_tile,
+           ROWS * 128 / us_tile * 1e-3, ROWS * 128 / us_tile * 1e-3 * grid * 1e-3);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) printf("  error: %s\n", hipGetErrorString(e));
+}
+
+int main() {
+    const int M = 2048, N = 1280, K = 1280;
+    f16 *A, *W;
+    float* sink;
+    hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&sink, 64);
+    std::vector<f16> h((size_t)M * K);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (f16)((float)(rand() % 2001 - 1000) * 1e-3f);
+    hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
+    hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+    for (int xr = 0; xr < 2; ++xr) {
+        run<0, 4, 3>("LDS-DMA 4 waves ring3 barrier", A, W, K, sink, xr, 256);
+        run<0, 8, 3>("LDS-DMA 8 waves ring3 barrier", A, W, K, sink, xr, 256);
+        run<0, 8, 4>("LDS-DMA 8 waves ring4 barrier", A, W, K, sink, xr, 256);
+        run<0, 14, 3>("LDS-DMA 14 waves ring3 barrier", A, W, K, sink, xr, 256);
+        run<0, 14, 5>("LDS-DMA 14 waves ring5 barrier", A, W, K, sink, xr, 256);
+        run<2, 4, 3>("LDS-DMA 4 waves free-run d3", A, W, K, sink, xr, 256);
+        run<2, 4, 5>("LDS-DMA 4 waves free-run d5", A, W, K, sink, xr, 256);
+        run<2, 8, 5>("LDS-DMA 8 waves free-run d5", A, W, K, sink, xr, 256);
+        run<2, 14, 5>("LDS-DMA 14 waves free-run d5", A, W, K, sink, xr, 256);
+        run<1, 4, 2>("reg + ds_write 4 waves", A, W, K, sink, xr, 256);
+        run<1, 8, 2>("reg + ds_write 8 waves", A, W, K, sink, xr, 256);
+        run<1, 14, 2>("reg + ds_write 14 waves", A, W, K, sink, xr, 256);
+        run<3, 4, 2>("reg only 4 waves", A, W, K, sink, xr, 256);
+        run<3, 8, 2>("reg only 8 waves", A, W, K, sink, xr, 256);
+        run<3, 14, 2>("reg only 14 waves", A, W, K, sink, xr, 256);
+    }
+    // one XCD's worth of workgroups only (32 CUs busy): is the limit per CU or per L2?
+    run<2, 8, 5>("LDS-DMA 8 waves free-run d5", A, W, K, sink, 1, 64);
+    run<3, 8, 2>("reg only 8 waves", A, W, K, sink, 1, 64);
+    return 0;
+}
