@@ -246,6 +246,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AGeo g) {
 
 constexpr float THR = 5.0f;
 
+// swizzle of the K tile image (16-byte chunk c of LDS row rho is stored at chunk c ^ KSWZ(rho)).  Rows are 128 bytes, so two rows
+// share a 256-byte bank row and a ds_read_b128 lane group (16 lanes = 16 different rows, same logical chunk) is conflict-free
+// only if (rho & 1, chunk) differs for all 16: (rho >> 1) & 7 does that for the 32-row fragment reads of this kernel (lane
+// groups {0-3, 12-15, 20-27}, ...); the first form, rho & 7, left every K fragment read two-way conflicted.
+#ifndef IIR_ATTN_KSWZ_OLD
+#define KSWZ(rho) (((rho) >> 1) & 7)
+#else
+#define KSWZ(rho) ((rho) & 7)
+#endif
+
 // One 64-key tile as TWO online-softmax steps of 32 keys (third form, round 2 late).  The 16 MFMAs of a tile used to sit in two
 // groups either side of the whole tile's vector work (row maximum over all 64 keys before the first exponential): a serial
 // chain  8 MFMA -> softmax -> 8 MFMA  in which neither pipe ever had the other's work to overlap with (5.3: a lone workgroup
@@ -260,7 +270,7 @@ __device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const 
                                           f32x16& negm, float& m, float& l, f32x16 (&o)[2], int qi, int hh) {
     auto scores = [&](int kb, const f32x16& c) {
         const char* krow = kt + (kb * 32 + qi) * 128;
-        const int sw = qi & 7;
+        const int sw = KSWZ(qi);
         f16x8 kf = *(const f16x8*)(krow + ((hh ^ sw) * 16));
         f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], c, 0, 0, 0);
 #pragma unroll
@@ -356,7 +366,7 @@ __device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const 
     f32x16 sb;
     {
         const char* krow = kt + (32 + qi) * 128;
-        const int sw = qi & 7;
+        const int sw = KSWZ(qi);
         f16x8 kf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const f16x8*)(krow + (((2 * ks + hh) ^ sw) * 16));
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
             const int rho = r0 + srow;
             int key = t * KT + ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1));
             if (key >= s.Tkv) key = s.Tkv - 1;
-            const int kc = spos ^ srow;
+            const int kc = spos ^ KSWZ(rho);
             glds16(kbase + (long)key * s.ldk + kc * 8, Ks + buf * KT * 128 + r0 * 128);
             const int d = r0 + srow;
             const int vc = spos ^ ((d >> 1) & 7);

@@ -29,7 +29,11 @@ using iir::Geo;
 constexpr int BK = 64;
 constexpr int PF_TOUCHES = 2;
 
-template <int BN>
+// V (schedule variant, A/B switch IIR_G8V): 0 = activation pieces requested in one block at the start of the tile; 1 = one
+// piece per sub-phase (activations in sub-phases 0..3, weights behind them); 2 = as 1, and waves 4-7 (the second wave of every
+// SIMD) issue a sub-phase's piece AFTER its MFMAs instead of before them, so the two waves of a SIMD do not sit in the
+// (~70-125 cycle) LDS-DMA issue at the same moment with the matrix pipe idle behind them
+template <int BN, int V>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
     using E = f16;
     using E4 = f16x4;
@@ -136,19 +140,30 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(B_PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
+    auto stage_a1 = [&](int t, int buf, int q) {
+        glds16(a_base + q * a_pstride + t * 128 + a_voff, smem + buf * STAGE + (q * 8 + wave) * 1024);
+    };
+    const bool late = V == 2 && wave >= 4;
     int cur = 0;
     for (int t = 0; t < nk; ++t) {
         const char* st = smem + cur * STAGE;
         read_b(st);
         read_a(st, 0, a0);
-        if (t + 1 < nk) stage_a(t + 1, cur ^ 1);          // the other stage's activation half: last read in tile t-1
-        const bool more_b = t + 2 < nk;
+        const bool more_a = t + 1 < nk, more_b = t + 2 < nk;
+        if (V == 0 && more_a) stage_a(t + 1, cur ^ 1);      // the other stage's activation half: last read in tile t-1
+        // piece of sub-phase i (V >= 1): activation pieces first (all of them are issued before the first weight piece, which
+        // is what the counted vmcnt at X relies on), the weight pieces only after Y (i >= 1)
+        auto piece = [&](int i) {
+            if (V == 0) { if (i >= 1 && i <= B_PIECES && more_b) stage_b1(t + 2, cur, i - 1); return; }
+            if (i < A_PIECES) { if (more_a) stage_a1(t + 1, cur ^ 1, i); }
+            if (i >= MI - B_PIECES && more_b) stage_b1(t + 2, cur, i - (MI - B_PIECES));
+        };
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             E8(&ac)[2] = (i & 1) ? a1 : a0;
             E8(&an)[2] = (i & 1) ? a0 : a1;
             if (i + 1 < MI) read_a(st, i + 1, an);
-            if (i >= 1 && i <= B_PIECES && more_b) stage_b1(t + 2, cur, i - 1);      // weight half of THIS stage: free since Y
+            if (!late) piece(i);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -156,6 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
                 for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[s][j], ac[s], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             if (i == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Y(t): every wave holds its weight fragments
+            if (late) piece(i);
         }
         // X(t+1): tile t+1 landed (activations requested a tile ago, weights two tiles ago; the weights of tile t+2 may still
         // be in flight), and every wave is done with tile t's stage
@@ -234,6 +250,21 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // chunk c staged (and chunk c-1's LDS reads long done)
+        if (g.Ct && n0 >= g.tr_from) {
+            // transposed write-out (the V third of a fused q|k|v projection -> the V^T image the attention kernel reads): a lane
+            // gathers 8 consecutive tile rows of one column from the staged chunk and stores them as 16 contiguous bytes of Ct
+            // (8 staged rows 8g .. 8g+7 are consecutive tile rows: they lie inside one 32-row run of a wave row)
+#pragma unroll 1
+            for (int p = tid; p < BN * (CHUNK_ROWS / 8); p += NT) {
+                const int col = p >> 3, gq = p & 7;
+                const long m = m0 + (gq >> 2) * WM + c * 32 + (gq & 3) * 8;
+                E8 o;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o[t] = (E)((float)*(const E*)(ct + (gq * 8 + t) * cs + col * 2) * g.out_scale);
+                *(E8*)(g.Ct + (long)(n0 + col - g.tr_from) * g.ldct + m) = o;
+            }
+            continue;
+        }
         // whole rows, 16 bytes per lane; staged row s = (wave row, row in its 32) -> tile row wmS * 128 + 32 c + (s & 31)
 #pragma unroll 1
         for (int p = tid; p < total; p += NT) {
@@ -253,8 +284,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA touches must land before the LDS is released
 }
 
-template <int BN>
-int launch8(const Geo& g0, hipStream_t stream) {
+template <int BN, int V>
+int launch8v(const Geo& g0, hipStream_t stream) {
     constexpr int BM = 256;
     Geo g = g0;
     g.tiles_m = g.M / BM;
@@ -274,11 +305,17 @@ int launch8(const Geo& g0, hipStream_t stream) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (attr_dev != dev) {
-        if (hipFuncSetAttribute((const void*)gemm8_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IIR_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)gemm8_kernel<BN, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IIR_ELAUNCH;
         attr_dev = dev;
     }
-    iir_launch(gemm8_kernel<BN>, dim3(8 * g.rm * g.rn), dim3(512), lds, stream, g);
+    iir_launch(gemm8_kernel<BN, V>, dim3(8 * g.rm * g.rn), dim3(512), lds, stream, g);
     return iir_launch_status();
+}
+
+template <int BN>
+int launch8(const Geo& g, hipStream_t stream) {
+    static const int v = getenv("IIR_G8V") ? atoi(getenv("IIR_G8V")) : 0;
+    return v == 2 ? launch8v<BN, 2>(g, stream) : v == 1 ? launch8v<BN, 1>(g, stream) : launch8v<BN, 0>(g, stream);
 }
 
 }  // namespace
@@ -287,7 +324,8 @@ namespace iir {
 
 bool gemm8_covers(const Geo& g, int bn) {
     if (bn != 320 && bn != 256) return false;
-    if (g.dtype != IIR_DT_F16 || g.c_f32 || g.Ct || g.ln_out || g.splitk == 2 || g.wscale || g.rowbias) return false;
+    if (g.dtype != IIR_DT_F16 || g.c_f32 || g.ln_out || g.splitk == 2 || g.wscale || g.rowbias) return false;
+    if (g.Ct && (g.epi != IIR_EPI_PLAIN || g.res || g.tr_from % bn || !g.ct_vec)) return false;      // transposed column range: whole tiles only
     if (g.epi != IIR_EPI_PLAIN && g.epi != IIR_EPI_GEGLU) return false;
     if (g.M % 256 || g.N % bn || g.K % 64 || g.K < 128) return false;
     if (!g.c_vec || (g.res && g.epi == IIR_EPI_PLAIN && !g.r_vec)) return false;

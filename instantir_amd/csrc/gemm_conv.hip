@@ -90,7 +90,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     f16* As = (f16*)smem;                       // [ST][BM][64]
     f16* Bs = As + ST * BM * BK;                // [ST][BN][64]  (W8: [ST][BN][64 bytes])
     constexpr int LOADS = A_INST + B_INST;      // LDS-DMA instructions per wave per stage (every wave issues exactly this many)
-    constexpr int SCRATCH_BYTES = LW ? 2048 : 1024;
+    constexpr int SCRATCH_BYTES = 256 * NW * (LW ? 2 : 1);        // 256 B per wave (prefetch touches, dummy loads)
     float2* rowstat = (float2*)(smem + RING_BYTES + SCRATCH_BYTES);          // [BM] (rstd, -rstd * mean) of this tile's rows (ln_in)
     constexpr int LNP_OFF = (BM * (2 * BN + 32) + 15) / 16 * 16;              // producer partials sit behind the finished output tile
     constexpr bool LN_OUT_FITS = LNP_OFF + BM * (BN / 8) * 8 <= RING_BYTES;
@@ -209,7 +209,11 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         }
         if (!W8) {
 #pragma unroll
-            for (int i = 0; i < B_INST; ++i) glds16(b_src[i] + k0, bs + (i * NW + wave) * 8 * BK);
+            for (int i = 0; i < B_INST; ++i) {
+                if (B_GROUPS % NW == 0 || i * NW + wave < B_GROUPS) glds16(b_src[i] + k0, bs + (i * NW + wave) * 8 * BK);
+                else     // (8-wave builds of the 160-wide tiles: 20 row groups over 8 waves) one 4-byte touch keeps the counted waits uniform
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g.W, (LDS_AS void*)(smem + RING_BYTES + wave * 256), 4, 0, 0);
+            }
         } else {
             char* bs8 = (char*)Bs + buf * B_STAGE_BYTES;
 #pragma unroll
@@ -682,7 +686,7 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + (LW ? 2048 : 1024) + BM * 8;   // ring (reused as the output tile) + prefetch scratch (256 B per wave) + LayerNorm row statistics
+    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 256 * WAVES_M * 2 * (LW ? 2 : 1) + BM * 8;   // ring (reused as the output tile) + prefetch scratch (256 B per wave) + LayerNorm row statistics
     if (g.ln_out) {         // producer of LayerNorm partials: whole tiles, 16-byte rows, plain epilogue (see the kernel's fast write-out path)
         constexpr bool fits = (BM * (2 * BN + 32) + 15) / 16 * 16 + BM * (BN / 8) * 8 <= ST * (BM * 128 + (W8 ? BN * 64 : BN * 128));
         if (!fits || conv || g.epi != IIR_EPI_PLAIN || g.c_f32 || g.Ct || g.splitk == 2 || g.M % BM || g.N % BN || !g.c_vec || (g.res && !g.r_vec))
@@ -818,7 +822,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // large-N linears whose 256 x 320 tiles fill the chip (the GEGLU projections): the 8-wave two-tile-deep kernel of
     // gemm8.hip (142 FLOP per staged byte against 71 for two 128x160 workgroups per CU).  IIR_G8=0 switches it off (A/B).
     static const bool g8_on = !(getenv("IIR_G8") && atoi(getenv("IIR_G8")) == 0);
-    if (tile == 0 && g8_on && !conv && g.K >= 640 && (long)(g.M / 256) * (g.N / 320) >= 192 && iir::gemm8_covers(g, 320))
+    if (tile == 0 && g8_on && !conv && g.K >= 640 && (long)(g.M / 256) * (g.N / 320) >= 256 && iir::gemm8_covers(g, 320))
         return iir::gemm8_launch(g, 320, stream);
     if (tile == 91 || tile == 92) return conv ? IIR_EINVAL : iir::gemm8_launch(g, tile == 91 ? 320 : 256, stream);
     if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
@@ -832,6 +836,9 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         // K = 5120 645 -> 707; the per-tile slope stays at the ~70 GB/s per-CU L2 -> LDS fill rate, the fixed part drops)
         static const bool lw_on = !(getenv("IIR_T5_LW") && atoi(getenv("IIR_T5_LW")) == 0);
         static const bool lw_conv = !(getenv("IIR_T5_LWCONV") && atoi(getenv("IIR_T5_LWCONV")) == 0);
+        static const bool lw2 = getenv("IIR_T5_LW2") && atoi(getenv("IIR_T5_LW2")) == 1;     // experiment: 2-stage loader-wave build (58 KB of LDS: two kernels can share a CU)
+        if (one_per_cu && lw2 && !conv && !g.wscale && g.splitk != 2) tile = 75;
+        else
         if (one_per_cu && lw_on && (!conv || (lw_conv && stages == 3)) && !g.wscale && g.splitk != 2 && stages >= 3 && stages <= 5) tile = stages == 3 ? 55 : stages == 4 ? 65 : 85;
         else
         tile += 10 * stages;
@@ -852,6 +859,10 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         case 75: return lw_launch<64, 160, 2>(g, conv, stream);
         case 85: return lw_launch<64, 160, 5>(g, conv, stream);
         case 34: return launch<128, 160, 3>(g, conv, stream);
+        case 56: return launch<64, 160, 3, 4>(g, conv, stream);    // 8 waves (4 x 2): two waves per SIMD on the one-per-CU tile
+        case 66: return launch<64, 160, 4, 4>(g, conv, stream);
+        case 57: return launch<128, 160, 3, 4>(g, conv, stream);
+        case 47: return launch<128, 160, 2, 4>(g, conv, stream);
         case 42: return launch<128, 64, 4>(g, conv, stream);
         case 26: return launch<256, 128, 2, 4>(g, conv, stream);   // 8 waves, 1 workgroup per CU
         case 36: return launch<256, 128, 3, 4>(g, conv, stream);

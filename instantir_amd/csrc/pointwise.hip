@@ -176,7 +176,9 @@ __global__ void transpose_kernel(const f16* in, long ldi, int rows, int cols, f1
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx over cols, by over rows
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
         const int r = by + j, c = bx + threadIdx.x;
-        tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * ldi + c] : (f16)0.f;
+        // unconditional load from a clamped address, then a select: no per-lane-predicated global_load (the form DESIGN.md 5.8 retires)
+        const f16 v = in[(long)min(r, rows - 1) * ldi + min(c, cols - 1)];
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? v : (f16)0.f;
     }
     __syncthreads();
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {

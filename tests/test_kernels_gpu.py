@@ -532,3 +532,118 @@ def test_groupnorm_reproducible_beside_a_conv(dev):
                 first = out
             else:
                 assert torch.equal(out, first), (R, HW, C, it)
+
+
+# ---- round 3: the 8-wave 256 x BN kernel (gemm8.hip) --------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,mode,tile", [(256, 320, 128, "plain", 91), (512, 640, 192, "res", 91), (512, 640, 256, "geglu", 91),
+                                             (256, 640, 320, "silu", 91), (512, 512, 256, "res", 92), (768, 960, 1280, "geglu", 91),
+                                             (2048, 10240, 1280, "geglu", 0)])
+def test_gemm8_tile(dev, M, N, K, mode, tile):
+    """256 x 320 / 256 x 256 output tile, 8 waves, two-tile-deep LDS-DMA pipeline, chunked epilogue: against torch fp32, and bit
+    for bit against the 4-wave kernel (same fp32 accumulation order per K step, same epilogue arithmetic).  tile = 0 with the
+    2048 x 10240 x 1280 GEGLU projection is the launch the engine's chooser sends to this kernel."""
+    from instantir_amd import ops
+    from instantir_amd.packing import pair_rows
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
+    geglu = mode == "geglu"
+    n_out = N // 2 if geglu else N
+    res = _rand(g, M, n_out) if mode == "res" else None
+    y = a.float() @ w.float().T + b.float()
+    if geglu:
+        want = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+        wd, bd = pair_rows(w[:N // 2], w[N // 2:]).to(dev), pair_rows(b[:N // 2], b[N // 2:]).to(dev)
+    else:
+        want = F.silu(y) if mode == "silu" else y
+        if res is not None:
+            want = want + res.float()
+        wd, bd = w.to(dev), b.to(dev)
+    kw = dict(bias=bd, epi=ops.EPI_GEGLU if geglu else ops.EPI_PLAIN, act=ops.ACT_SILU if mode == "silu" else ops.ACT_NONE)
+    if res is not None:
+        kw["res"] = res.to(dev)
+    out, old = (torch.zeros(M, n_out, dtype=torch.half, device=dev) for _ in range(2))
+    ops.gemm(a.to(dev), wd, out, tile=tile, **kw)
+    ops.gemm(a.to(dev), wd, old, tile=24, **kw)                 # 128 x 160, 4 waves
+    torch.cuda.synchronize()
+    tol = 8e-3 if geglu else 3e-3
+    _close(out, want, rtol=tol, atol=tol, what=f"gemm8 {mode}")
+    assert torch.equal(out, old), "gemm8 differs from the 4-wave kernel"
+
+
+def test_gemm8_transposed_v_and_layernorm_fold(dev):
+    """The fused q|k|v projection on the 256 x 320 tile: LayerNorm folded in (`ln_in`), the V third written transposed."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, C = 512, 320
+    a0, w0 = _rand(g, M, C), _rand(g, C, C, scale=C ** -0.5)
+    gamma, beta = (1.0 + 0.2 * torch.randn(C, generator=g)).half(), (0.3 * torch.randn(C, generator=g)).half()
+    w, b = _rand(g, 3 * C, C, scale=C ** -0.5), _rand(g, 3 * C)
+    stats = torch.zeros(ops.ln_parts(M, C, C), M, 2, dtype=torch.float32, device=dev)
+    h = torch.empty(M, C, dtype=torch.half, device=dev)
+    ops.gemm(a0.to(dev), w0.to(dev), h, ln_out=stats)
+    fold = ops.LnFold(w.to(dev), gamma.to(dev), beta.to(dev), bias=b.to(dev), eps=1e-5)
+    qk = torch.zeros(M, 2 * C, dtype=torch.half, device=dev)
+    vt = torch.zeros(C, M, dtype=torch.half, device=dev)
+    ops.gemm(h, fold.w, qk, bias=fold.bias, tile=91, out_t=(vt, 2 * C), ln_in=(stats, fold.colsum, fold.eps))
+    torch.cuda.synchronize()
+    y = F.layer_norm(h.float().cpu(), (C,), gamma.float(), beta.float(), 1e-5) @ w.float().T + b.float()
+    _close(qk, y[:, :2 * C], rtol=4e-3, atol=4e-3, what="q|k")
+    _close(vt, y[:, 2 * C:].T, rtol=4e-3, atol=4e-3, what="V^T")
+
+
+def test_gemm8_rejects_what_it_does_not_cover(dev):
+    from instantir_amd import ops
+    a = torch.zeros(300, 128, dtype=torch.half, device=dev)             # M not a multiple of 256
+    w = torch.zeros(320, 128, dtype=torch.half, device=dev)
+    with pytest.raises(Exception):
+        ops.gemm(a, w, torch.zeros(300, 320, dtype=torch.half, device=dev), tile=91)
+
+
+# ---- round 3: the large-grid attention builds and the pre-staged short-KV form ---------------------------------------------
+@pytest.mark.parametrize("T", [4096, 8192])
+def test_self_attention_large_grid(dev, T):
+    """T = 4096 (the level-1 self-attention of the step: 3 waves per SIMD build, the one with spilled registers) and T = 8192
+    (the Aggregator's): B = 1, 2 heads would only make 64 / 128 workgroups, so the grid is widened to the step's own size
+    with B = 2, 10 heads and ONE (batch, head) pair is checked against fp32 SDPA, the others against the first kernel
+    generation-independent property that equal inputs give equal outputs."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(T)
+    B, heads = 2, 10
+    C = heads * 64
+    pair = _rand(g, 3, T, 64)                                    # q, k, v of one (batch, head) pair, copied into every pair
+    q = pair[0].repeat(B, heads).reshape(B * T, C).contiguous().to(dev)
+    k = pair[1].repeat(B, heads).reshape(B * T, C).contiguous().to(dev)
+    vt = pair[2].T.contiguous().repeat(heads, B).to(dev)          # (C, B*T): V^T of every pair
+    o = torch.empty(B * T, C, dtype=torch.half, device=dev)
+    ops.attention(q, o, [(k, T, vt, T, T)], B, heads, T)
+    torch.cuda.synchronize()
+    want = _sdpa_ref(pair[0][None], pair[1][None], pair[2][None], 1).reshape(T, 64)
+    got = o.reshape(B, T, heads, 64)
+    _close(got[0, :, 0], want, rtol=3e-3, atol=3e-3, what=f"attention T={T}")
+    for b_ in range(B):
+        for h_ in range(heads):
+            assert torch.equal(got[b_, :, h_], got[0, :, 0]), "identical (batch, head) pairs gave different outputs"
+
+
+@pytest.mark.parametrize("T", [1024, 4096])
+def test_cross_attention_prestaged(dev, T):
+    """Text (77) + IP (64) keys: 3 tiles in all, the pre-staged form (every tile requested at entry, one wait) at the step's
+    query counts."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(T + 1)
+    B, heads = 2, 4
+    C = heads * 64
+    q = _rand(g, B, T, C)
+    segs, want = [], 0
+    for L in (77, 64):
+        k, v = _rand(g, B, L, C), _rand(g, B, L, C)
+        tp = (L + 7) // 8 * 8
+        vt = torch.zeros(C, B * tp, dtype=torch.half, device=dev)
+        for b_ in range(B):
+            vt[:, b_ * tp:b_ * tp + L] = v[b_].T.to(dev)
+        segs.append((k.reshape(-1, C).to(dev), L, vt, tp, L))
+        want = want + _sdpa_ref(q, k, v, heads)
+    o = torch.empty(B * T, C, dtype=torch.half, device=dev)
+    ops.attention(q.reshape(-1, C).to(dev), o, segs, B, heads, T)
+    torch.cuda.synchronize()
+    _close(o, want.reshape(B * T, C), rtol=3e-3, atol=3e-3, what="text + IP cross-attention")

@@ -59,8 +59,55 @@ def case(M, N, K, geglu, fold, res, act=ops.ACT_NONE, tile_new=91, tile_old=24, 
     return same
 
 
+def case_qkv(M, C, fold=True, time_it=True):
+    """fused q|k|v projection: columns >= 2C leave the GEMM transposed (out_t)."""
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    N, K = 3 * C, C
+    a = torch.randn(M, K, generator=g).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
+    b = torch.randn(N, generator=g).half().to(dev)
+    kw = {}
+    if fold:
+        gam, bet = (torch.randn(K, generator=g) * 0.2 + 1).half().to(dev), (torch.randn(K, generator=g) * 0.1).half().to(dev)
+        f = ops.LnFold(w.float(), gam, bet, bias=b.float())
+        st = torch.zeros(ops.ln_parts(M, K, K), M, 2, device=dev)
+        h = torch.empty(M, K, device=dev, dtype=torch.half)
+        ops.gemm(a, (torch.randn(K, K, generator=g) * K ** -0.5).half().to(dev), h, ln_out=st)
+        a, w, b = h, f.w, f.bias
+        kw["ln_in"] = (st, f.colsum, 1e-5)
+    outs = []
+    for tile in (21, 91):
+        qk = torch.zeros(M, 2 * C, device=dev, dtype=torch.half); vt = torch.zeros(C, M, device=dev, dtype=torch.half)
+        ops.gemm(a, w, qk, bias=b, tile=tile, out_t=(vt, 2 * C), **kw)
+        outs.append((qk, vt))
+    torch.cuda.synchronize()
+    same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    msg = f"qkv M={M} C={C} fold={int(fold)}: bit-equal={same}"
+    if time_it:
+        qk, vt = outs[0]
+        ts = [timeit(lambda: ops.gemm(a, w, qk, bias=b, tile=t_, out_t=(vt, 2 * C), **kw)) for t_ in (21, 0, 91)]
+        msg += f" | t21 {ts[0]:6.1f} us  auto {ts[1]:6.1f} us  t91 {ts[2]:6.1f} us ({2 * M * N * K / ts[2] / 1e6:5.0f} TF)"
+    print(msg, flush=True)
+    return same
+
+
 if __name__ == "__main__":
     ok = True
+    if "qkv" in sys.argv:
+        ok &= case_qkv(512, 320, time_it=False)
+        ok &= case_qkv(8192, 640)
+        ok &= case_qkv(16384, 640)
+        ok &= case_qkv(2048, 1280)
+        print("ALL BIT-EQUAL" if ok else "MISMATCH")
+        sys.exit(0)
+    if "quick" in sys.argv:
+        ok &= case(512, 640, 256, True, False, False, time_it=False)
+        ok &= case(2048, 10240, 1280, True, True, False)
+        ok &= case(4096, 10240, 1280, True, True, False)
+        ok &= case(8192, 5120, 640, True, True, False)
+        ok &= case(8192, 7680, 8192, False, False, False, tile_new=91)
+        print("ALL BIT-EQUAL" if ok else "MISMATCH")
+        sys.exit(0)
     ok &= case(256, 320, 128, False, False, False, time_it=False)
     ok &= case(512, 640, 192, False, False, True, time_it=False)
     ok &= case(512, 640, 256, True, False, False, time_it=False)

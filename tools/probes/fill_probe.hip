@@ -21,7 +21,7 @@ constexpr int BM = 64, BN = 160, ROWS = BM + BN;   // 224 rows of 128 B per K ti
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE, int NW, int ST>
+template <int MODE, int NW, int ST, int TPB = 1>
 __global__ __launch_bounds__(NW * 64) void fill_kernel(const f16* __restrict__ A, const f16* __restrict__ W, int K, int reps, float* sink, int xcd_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NW * 64) void fill_kernel(const f16* __restrict__ A
             __syncthreads();
         }
         acc += r0[0][0];
-    } else {
+    } else if constexpr (MODE == 3) {
         f32x4 r0[PPW], r1[PPW];
         auto ld = [&](int t, f32x4 (&r)[PPW]) {
             const int k0 = (t % nk) * 64;
@@ -120,16 +120,96 @@ __global__ __launch_bounds__(NW * 64) void fill_kernel(const f16* __restrict__ A
             for (int i = 0; i < PPW; ++i) acc += r1[i][0] + r1[i][3];
         }
     }
+    if constexpr (MODE >= 4) {
+        // waves [0, 4): loaders (ring of ST stages, counted vmcnt, one barrier per tile); waves [4, 8): compute stand-ins
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        constexpr int LPW = PIECES / 4;     // 7 pieces per loader wave
+        constexpr int GB = TPB * ROWS * 128; // bytes of one ring slot (TPB tiles)
+        const int groups = total / TPB;
+        if (wave < 4) {
+            __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 2048 * K * 2, 0x00020000);
+            __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 1280 * K * 2, 0x00020000);
+            const int voff = srow * K * 2 + schunk * 16;          // per lane, the same for every piece and tile
+            if constexpr (MODE == 10) __builtin_amdgcn_s_setprio(3);
+            auto stage = [&](int gidx, int slot) {
+#pragma unroll
+                for (int u = 0; u < TPB; ++u) {
+                    const int k0 = ((gidx * TPB + u) % nk) * 64;
+#pragma unroll
+                    for (int i = 0; i < LPW; ++i) {
+                        const int p = i * 4 + wave, r = p * 8 + srow;
+                        if constexpr (MODE == 9 || MODE == 10) {
+                            // scalar piece offset: the loader's loop has no vector ALU instruction at all
+                            const int r0 = p * 8;
+                            if (r0 < BM) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_AS void*)(smem + slot * GB + u * ROWS * 128 + p * 1024), 16, voff, ((tm * BM + r0) * K + k0) * 2, 0, 0);
+                            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (LDS_AS void*)(smem + slot * GB + u * ROWS * 128 + p * 1024), 16, voff, ((tn * BN + r0 - BM) * K + k0) * 2, 0, 0);
+                        } else {
+                            const f16* sp = r < BM ? A + (long)(tm * BM + r) * K + schunk * 8 : W + (long)(tn * BN + (r - BM)) * K + schunk * 8;
+                            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sp + k0), (LDS_AS void*)(smem + slot * GB + u * ROWS * 128 + p * 1024), 16, 0, 0);
+                        }
+                    }
+                }
+            };
+#pragma unroll
+            for (int s2 = 0; s2 < ST - 1; ++s2) stage(s2, s2);
+            int cur = 0;
+            for (int t = 0; t < groups; ++t) {
+                wait_vm<(ST - 2) * LPW * TPB>();
+                __builtin_amdgcn_s_barrier();
+                stage(t + ST - 1, (cur + ST - 1) % ST);
+                cur = cur + 1 == ST ? 0 : cur + 1;
+            }
+            wait_vm<0>();
+        } else {
+            h8 a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
+            f4 c4[10];
+            f16v c16[5];
+            for (int i = 0; i < 10; ++i) c4[i] = (f4){0, 0, 0, 0};
+            for (int i = 0; i < 5; ++i) for (int j = 0; j < 16; ++j) c16[i][j] = 0;
+            int cur = 0;
+            for (int t = 0; t < groups; ++t) {
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int u = 0; u < TPB; ++u) {
+                    if constexpr (MODE == 6 || MODE == 7 || MODE == 9 || MODE == 10) {
+                        // the GEMM's conflict-free fragment reads: row frow of a 16-row group, chunk (4 s + fq) ^ (frow & 7); 7 groups x 2 k-steps
+                        const int frow = lane & 15, fq = lane >> 4;
+                        const char* base = smem + cur * GB + u * ROWS * 128 + frow * 128;
+#pragma unroll
+                        for (int i = 0; i < 14; ++i) { h8 v = *(const h8*)(base + (i >> 1) * 2048 + ((((i & 1) * 4 + fq) ^ (frow & 7)) * 16)); a[i & 7] += v[i & 7]; }
+                    }
+                    if constexpr (MODE == 4 || MODE == 7 || MODE == 9 || MODE == 10) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int i = 0; i < 10; ++i) c4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c4[i], 0, 0, 0);
+                    }
+                    if constexpr (MODE == 5) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) c16[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c16[i], 0, 0, 0);
+                    }
+                }
+                cur = cur + 1 == ST ? 0 : cur + 1;
+            }
+            for (int i = 0; i < 10; ++i) acc += c4[i][0];
+            for (int i = 0; i < 5; ++i) acc += c16[i][0];
+            acc += (float)a[0];
+        }
+    }
     __syncthreads();
     acc += ((const float*)smem)[tid];
     if (acc == 123.456f) sink[0] = acc;
 }
 
-template <int MODE, int NW, int ST>
+template <int MODE, int NW, int ST, int TPB = 1>
 void run(const char* name, const f16* A, const f16* W, int K, float* sink, int xcd_rows, int grid) {
     const int reps = 40;
-    const size_t lds = (MODE == 1 ? 2 : ST) * ROWS * 128 > 90 * 1024 ? (size_t)ST * ROWS * 128 : 90 * 1024;   // >= 90 KiB: one workgroup per CU
-    auto k = fill_kernel<MODE, NW, ST>;
+    const size_t lds = (size_t)(MODE == 1 ? 2 : ST) * TPB * ROWS * 128 > 90 * 1024 ? (size_t)ST * TPB * ROWS * 128 : 90 * 1024;   // >= 90 KiB: one workgroup per CU
+    auto k = fill_kernel<MODE, NW, ST, TPB>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -149,7 +229,7 @@ void run(const char* name, const f16* A, const f16* W, int K, float* sink, int x
     if (e != hipSuccess) printf("  error: %s\n", hipGetErrorString(e));
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int M = 2048, N = 1280, K = 1280;
     f16 *A, *W;
     float* sink;
@@ -158,24 +238,31 @@ int main() {
     for (size_t i = 0; i < h.size(); ++i) h[i] = (f16)((float)(rand() % 2001 - 1000) * 1e-3f);
     hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
     hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+    if (argc > 1) {   // loader / compute co-issue: what slows the LDS-DMA issue of the loader-wave GEMM (880 cycles per K tile against 480 here)?
+        run<0, 4, 3>("LDS-DMA 4 waves ring3 barrier (loaders alone)", A, W, K, sink, 1, 256);
+        run<4, 8, 3>("4 loaders + 4 waves x 20 mfma16x16x32", A, W, K, sink, 1, 256);
+        run<5, 8, 3>("4 loaders + 4 waves x 10 mfma32x32x16", A, W, K, sink, 1, 256);
+        run<6, 8, 3>("4 loaders + 4 waves x 14 ds_read_b128", A, W, K, sink, 1, 256);
+        run<7, 8, 3>("4 loaders + 4 waves x (14 reads + 20 mfma16)", A, W, K, sink, 1, 256);
+        run<7, 8, 4>("same, ring of 4 tiles", A, W, K, sink, 1, 256);
+        run<7, 8, 2, 2>("same, 2 tiles per barrier, ring 2x2", A, W, K, sink, 1, 256);
+        run<9, 8, 3>("reads + mfma16, loaders by buffer_load..lds with scalar offsets", A, W, K, sink, 1, 256);
+        run<10, 8, 3>("same, loaders at s_setprio 3", A, W, K, sink, 1, 256);
+        run<9, 8, 2, 2>("buffer loaders, 2 tiles per barrier, ring 2x2", A, W, K, sink, 1, 256);
+        run<0, 4, 3>("LDS-DMA 4 waves ring3 barrier (loaders alone)", A, W, K, sink, 1, 256);
+        return 0;
+    }
     for (int xr = 0; xr < 2; ++xr) {
         run<0, 4, 3>("LDS-DMA 4 waves ring3 barrier", A, W, K, sink, xr, 256);
         run<0, 8, 3>("LDS-DMA 8 waves ring3 barrier", A, W, K, sink, xr, 256);
-        run<0, 8, 4>("LDS-DMA 8 waves ring4 barrier", A, W, K, sink, xr, 256);
         run<0, 14, 3>("LDS-DMA 14 waves ring3 barrier", A, W, K, sink, xr, 256);
-        run<0, 14, 5>("LDS-DMA 14 waves ring5 barrier", A, W, K, sink, xr, 256);
-        run<2, 4, 3>("LDS-DMA 4 waves free-run d3", A, W, K, sink, xr, 256);
         run<2, 4, 5>("LDS-DMA 4 waves free-run d5", A, W, K, sink, xr, 256);
-        run<2, 8, 5>("LDS-DMA 8 waves free-run d5", A, W, K, sink, xr, 256);
         run<2, 14, 5>("LDS-DMA 14 waves free-run d5", A, W, K, sink, xr, 256);
         run<1, 4, 2>("reg + ds_write 4 waves", A, W, K, sink, xr, 256);
-        run<1, 8, 2>("reg + ds_write 8 waves", A, W, K, sink, xr, 256);
         run<1, 14, 2>("reg + ds_write 14 waves", A, W, K, sink, xr, 256);
         run<3, 4, 2>("reg only 4 waves", A, W, K, sink, xr, 256);
-        run<3, 8, 2>("reg only 8 waves", A, W, K, sink, xr, 256);
         run<3, 14, 2>("reg only 14 waves", A, W, K, sink, xr, 256);
     }
-    // one XCD's worth of workgroups only (32 CUs busy): is the limit per CU or per L2?
     run<2, 8, 5>("LDS-DMA 8 waves free-run d5", A, W, K, sink, 1, 64);
     run<3, 8, 2>("reg only 8 waves", A, W, K, sink, 1, 64);
     return 0;

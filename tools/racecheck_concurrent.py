@@ -27,7 +27,8 @@ bad = []
 def screen(name, launch, shapes, dtype=torch.half):
     first = None; nd = 0; where = None
     for it in range(REP):
-        outs = [torch.zeros(s, dtype=dtype, device=dev) for s in shapes]
+        dts = list(dtype) if isinstance(dtype, (list, tuple)) else [dtype] * len(shapes)
+        outs = [torch.zeros(s, dtype=dt_, device=dev) for s, dt_ in zip(shapes, dts)]
         if NOISE: noise(3)
         launch(*outs)
         torch.cuda.synchronize()
@@ -126,4 +127,34 @@ wsm = ops.gn_workspace(dev, 2, 32)
 screen("groupnorm R=2 HW=64 C=1280 (8x8 map)", lambda o: ops.groupnorm(gsm, o, 2, 64, gsg, gsb, 1e-5, True, 32, wsm), [(128, 1280)])
 lx, lg, lb = rnd(2048, 1280), rnd(1280) + 1, rnd(1280)
 screen("layernorm 2048x1280", lambda o: ops.layernorm(lx, o, lg, lb, 1e-5), [(2048, 1280)])
+# ---- round 3 additions: the kernels the first screen left out, and the 8-wave GEMM
+for (M8, N8, K8, geglu8) in [(2048, 10240, 1280, True), (4096, 10240, 1280, True), (8192, 5120, 640, True), (2048, 10240, 1280, False)]:
+    x8, w8, b8 = rnd(M8, K8), rnd(N8, K8, scale=K8 ** -0.5), rnd(N8)
+    if geglu8:
+        w8, b8 = pair_rows(w8[:N8 // 2], w8[N8 // 2:]), pair_rows(b8[:N8 // 2], b8[N8 // 2:])
+    screen(f"gemm8 (256x320, 8 waves) {M8}x{N8}x{K8} {'GEGLU' if geglu8 else 'plain'}",
+           lambda o: ops.gemm(x8, w8, o, bias=b8, tile=91, epi=ops.EPI_GEGLU if geglu8 else ops.EPI_PLAIN), [(M8, N8 // 2 if geglu8 else N8)])
+tx = rnd(154, 1280)
+screen("transpose 154x1280 -> (1280, 160)", lambda o: ops.transpose(tx, o, 160), [(1280, 160)])
+# adaLN batch: 8 jobs of the step's geometry (2 rows x 64 IP tokens, C = 1280 / 640), half of them transposed
+ada_x = [rnd(128, Cj) for Cj in (1280, 640) * 4]
+ada_sh, ada_sc = rnd(2, 2 * 1280 * 8), None
+def ada_launch(*outs):
+    jobs = []
+    for j, (xj, oj) in enumerate(zip(ada_x, outs)):
+        Cj = xj.shape[1]
+        jobs.append((xj, oj, ada_sh[:, j * 2560:j * 2560 + Cj], ada_sh[:, j * 2560 + 1280:j * 2560 + 1280 + Cj], j % 2 == 1))
+    tab = ops.adaln_job_table(jobs, dev)
+    ops.adaln_batch(tab, len(jobs), 128, 1280, ada_sh.stride(0), 64, 64, 64)
+    torch.cuda.synchronize()
+screen("adaln_batch 8 jobs (4 transposed)", ada_launch, [((Cj, 128) if j % 2 == 1 else (128, Cj)) for j, Cj in enumerate((1280, 640) * 4)])
+sm_s = (torch.randn(4096, 4096, generator=g) * 3).to(dev)
+screen("softmax_rows_f32 4096x4096 -> bf16", lambda o: ops.softmax_rows_f32(sm_s, o), [(4096, 4096)], dtype=torch.bfloat16)
+bl_a = torch.randn(1, 3, 1024, 1024, generator=g).to(dev)
+bl_b0 = torch.randn(1, 3, 1024, 1024, generator=g).to(dev)
+screen("blend_tiles (vertical, 256 rows)", lambda o: (o.copy_(bl_b0), ops.blend_tiles(bl_a, o, 256, True)), [(1, 3, 1024, 1024)], dtype=torch.float32)
+screen("lcm_step (rep 2, with fp32 preview)", lambda o, p32: ops.lcm_step(eps2, 1, 2, lcoef, xl, o, p32), [(2 * 128 * 128, 64), (2, 4, 128, 128)], dtype=[torch.half, torch.float32])
+fac = torch.ones(1, device=dev)
+screen("cfg_rescale_factor", lambda o: (ops.cfg_rescale_factor(eps2, 1, coef, xl, 0.7, fac), o.copy_(fac)), [(1,)], dtype=torch.float32)
+screen("unpack_latent", lambda o: ops.unpack_latent(eps2, o), [(2, 4, 128, 128)], dtype=torch.float32)
 print("kernels with run-to-run differences:", bad)
