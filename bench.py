@@ -53,6 +53,69 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def synth_encoder_weights(model_cls, cfg, dev, seed):
+    """Random weights with the exact inventory (names, shapes) of a transformers architecture: the class is instantiated on the
+    meta device (no allocation, no checkpoint -- none exist offline) and every tensor is drawn on the GPU."""
+    with torch.device("meta"):
+        m = model_cls(cfg)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    sd = {}
+    for k, v in m.state_dict().items():
+        if not v.dtype.is_floating_point:
+            continue
+        if v.ndim == 1 and ("norm" in k or "layrnorm" in k) and k.endswith("weight"):
+            t = 1.0 + 0.05 * torch.randn(v.shape, generator=g, device=dev)
+        elif "lambda1" in k:
+            t = 0.5 + 0.5 * torch.rand(v.shape, generator=g, device=dev)
+        elif v.ndim == 1:
+            t = 0.02 * torch.randn(v.shape, generator=g, device=dev)
+        elif "embed" in k or "cls_token" in k:
+            t = 0.05 * torch.randn(v.shape, generator=g, device=dev)
+        else:
+            t = torch.randn(v.shape, generator=g, device=dev) * (v.shape[-1] if v.ndim == 2 else v[0].numel()) ** -0.5
+        sd[k] = t.half()
+    return sd
+
+
+def end_to_end_leg(pipe, cfg, hv, dev, px, lcm, seed):
+    """One real `pipe(...)` call as infer.py makes it (/root/reference infer.py:211-225): a 1024 x 1024 PIXEL image in, pixels out,
+    30 DDIM steps, cfg 7.0 -- DINOv2-L + zero-image features, both CLIP text encoders (prompt given as token ids: no tokenizer
+    vocabulary exists offline), Resampler + per-image hoists (`prepare`), the loop, VAE encode and decode.  Returns seconds per
+    image of the SECOND call (the first one pays one-time set-up: arena sizing, kernel attribute calls)."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection, Dinov2Config, Dinov2Model
+    from instantir_amd.encoders import HipCLIPText, HipDinov2
+    pipe.vae = hv
+    pipe.image_encoder = HipDinov2(synth_encoder_weights(Dinov2Model, Dinov2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                                                                                   patch_size=14, image_size=518, mlp_ratio=4), dev, seed + 10), dev)
+    c1 = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                        max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768)
+    c2 = CLIPTextConfig(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
+                        max_position_embeddings=77, hidden_act="gelu", projection_dim=1280)
+    pipe.text_encoder = HipCLIPText(synth_encoder_weights(CLIPTextModelWithProjection, c1, dev, seed + 11), dev, hidden_act="quick_gelu", eos_token_id=49407)
+    pipe.text_encoder_2 = HipCLIPText(synth_encoder_weights(CLIPTextModelWithProjection, c2, dev, seed + 12), dev, hidden_act="gelu", eos_token_id=49407)
+    rs = np.random.RandomState(seed)
+    img = Image.fromarray(rs.randint(0, 256, (px, px, 3), dtype=np.uint8))
+    ids = torch.full((1, 77), 49407, dtype=torch.long)
+    ids[0, 0] = 49406
+    ids[0, 1:12] = torch.from_numpy(rs.randint(1000, 40000, 11))
+    nids = torch.full((1, 77), 49407, dtype=torch.long)
+    nids[0, 0] = 49406
+    kw = dict(image=img, prompt_ids=ids, prompt_ids_2=ids, negative_prompt_ids=nids, negative_prompt_ids_2=nids,
+              num_inference_steps=30, guidance_scale=7.0, previewer_scheduler=lcm, output_type="pt",
+              generator=torch.Generator(device=dev).manual_seed(seed))
+    out = pipe(**kw).images
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = pipe(**kw).images
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.isfinite(out).all().item()) and tuple(out.shape) == (1, 3, px, px)
+    pipe.vae = pipe.image_encoder = pipe.text_encoder = pipe.text_encoder_2 = None
+    return dt, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +127,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end pipe(...) call (images/s measured)")
     ap.add_argument("--no-inkernel-prefetch", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no encoder/previewer overlap)")
     ap.add_argument("--config", type=int, default=1, choices=[1, 4],
@@ -183,12 +247,14 @@ def main():
     run(args.steps, args.warmup)
     torch.cuda.synchronize()
     parallel.barrier()
-    dt = parallel.max_over_ranks(time.perf_counter() - t1, dev)
+    dt_local = time.perf_counter() - t1
+    dt = parallel.max_over_ranks(dt_local, dev)
+    rank_ms = [round(v / args.steps * 1e3, 3) for v in parallel.gather_floats(dt_local, dev)]      # a straggler shows here
     finite = bool(torch.isfinite(x).all().item())
     log(f"timed: {dt / args.steps * 1e3:.2f} ms/step")
 
     # ---- VAE legs (once per image, outside the step metric): full SDXL VAE geometry ----------------------
-    vae_ms = None
+    vae_ms = e2e = None
     if rank == 0 and not args.tiny and not args.no_vae:
         from instantir_amd.config import VAEConfig
         from instantir_amd.vae import HipVAE
@@ -203,6 +269,16 @@ def main():
         tv = time.perf_counter(); hv.encode(px_img, eps_l); torch.cuda.synchronize(); enc_ms = (time.perf_counter() - tv) * 1e3
         vae_ms = {"decode_ms": round(dec_ms, 2), "encode_ms": round(enc_ms, 2)}
         log(f"vae decode {dec_ms:.1f} ms, encode {enc_ms:.1f} ms")
+        if not args.no_e2e and args.size == 1024:
+            try:
+                e2e_s, e2e_ok = end_to_end_leg(pipe, cfg, hv, dev, px, lcm, seed + 20)
+                e2e = {"seconds_per_image": round(e2e_s, 4), "images_per_s": round(1.0 / e2e_s, 4), "finite_and_shaped": e2e_ok,
+                       "what": "pipe(image=PIL 1024x1024, prompt_ids=..., 30 steps, cfg 7.0, output_type='pt'): DINOv2-L + CLIP-L/bigG + "
+                               "Resampler + prepare + loop + VAE encode/decode, second call"}
+                log(f"end-to-end pipe(...) call: {e2e_s:.3f} s per image")
+            except Exception as ex:      # (transformers / PIL missing on the box: say so instead of failing the bench line)
+                e2e = {"seconds_per_image": None, "images_per_s": None, "error": f"{type(ex).__name__}: {ex}"[:300]}
+                log(f"end-to-end leg failed: {ex}")
         del hv
         torch.cuda.empty_cache()
 
@@ -279,6 +355,8 @@ def main():
                        "algorithmic_tflops_per_gpu": (round({512: 9.16, 1024: STEP_TFLOP, 2048: 225.85}[args.size] * args.steps / dt, 1)
                                                       if args.size in (512, 1024, 2048) and not args.tiny else None),
                        "images_per_s_30step": round(world / (30 * dt / args.steps + (((vae_ms or {}).get("decode_ms", 0) + (vae_ms or {}).get("encode_ms", 0)) * 1e-3)), 4),
+                       "images_per_s_measured": (e2e or {}).get("images_per_s"), "end_to_end": e2e,
+                       "ms_per_step_by_rank": rank_ms,
                        "vae": vae_ms, "finite": finite,
                        "setup_s": round(setup_s, 1), "world": world, "ranks": ranks_info, "weight_broadcast": bcast},
             "roofline": roof, "cpu_baseline": cpu,

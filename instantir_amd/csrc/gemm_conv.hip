@@ -711,31 +711,38 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
         if (best < 0. || cost < best) { best = cost; g.xm = xm; g.rm = rm; g.rn = rn; }
     }
     const dim3 grid(8 * g.rm * g.rn * (g.splitk == 2 ? 2 : 1)), block(128 * WAVES_M * (LW ? 2 : 1));
+    // dynamic LDS above 64 KB needs the function attribute ON THE DEVICE THE LAUNCH GOES TO: tracked per device and kernel
+    // instantiation (a function-local static used to run it once, for whichever device was current at the first launch)
+    auto ensure_lds = [&](const void* fn) -> bool {
+        static unsigned long long done[64] = {};           // one bit per device, per instantiation of this launcher x {gemm, conv}
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+        const int slot = conv ? 1 : 0;
+        if (done[dev] & (1ull << slot)) return true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        done[dev] |= 1ull << slot;
+        return true;
+    };
     if constexpr (W8) {
-        static const hipError_t attr_8 = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (function-local static: initialised once, thread-safe)
-        (void)attr_8;
+        if (!ensure_lds((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>)) return IIR_ELAUNCH;
         iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, grid, block, lds, stream, g);
         return iir_launch_status();
     } else if constexpr (LW) {
         if (g.splitk == 2) return IIR_EINVAL;
         if (conv) {
-            static const hipError_t attr_lc = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)attr_lc;
+            if (!ensure_lds((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M, false, true>)) return IIR_ELAUNCH;
             iir_launch(gemm_kernel<E, BM, BN, ST, true, WAVES_M, false, true>, grid, block, lds, stream, g);
         } else {
-            static const hipError_t attr_l = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)attr_l;
+            if (!ensure_lds((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>)) return IIR_ELAUNCH;
             iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, true>, grid, block, lds, stream, g);
         }
         return iir_launch_status();
     } else
     if (conv) {
-        static const hipError_t attr_c = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (function-local static: initialised once, thread-safe)
-        (void)attr_c;
+        if (!ensure_lds((const void*)gemm_kernel<E, BM, BN, ST, true, WAVES_M>)) return IIR_ELAUNCH;
         iir_launch(gemm_kernel<E, BM, BN, ST, true, WAVES_M>, grid, block, lds, stream, g);
     } else {
-        static const hipError_t attr_g = hipFuncSetAttribute((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (function-local static: initialised once, thread-safe)
-        (void)attr_g;
+        if (!ensure_lds((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M>)) return IIR_ELAUNCH;
         iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M>, grid, block, lds, stream, g);
     }
     return iir_launch_status();

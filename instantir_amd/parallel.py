@@ -97,6 +97,16 @@ def max_over_ranks(x: float, device) -> float:
     return float(t.item())
 
 
+def gather_floats(x: float, device):
+    """Every rank's value of `x`, in rank order (a one-element list without a process group)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

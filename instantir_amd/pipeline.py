@@ -6,9 +6,13 @@ error conventions for the checks it implements, same outputs.  The hot loop (:14
 HIP kernel launches, optionally replayed from a hipGraph per loop phase.
 
 Observable deviations, all documented in SURVEY.md Appendix C and DESIGN.md:
-  Q2  steps whose cond_scale is <= 0.1 everywhere run the UNet without residuals (the reference
-      multiplies the previous step's residuals by 0); on step 0 that raises a clear error instead
-      of the reference's NameError.
+  Q2  a step whose cond_scale is <= 0.1 everywhere skips previewer and Aggregator and, as the reference's statements do
+      (:1602-1603 run unconditionally), re-scales the PREVIOUS step's already scaled residuals (loop phase `unet_res`); the
+      adds are skipped only when that compound scale is zero for every image (same result).  On step 0 there are no previous
+      residuals: a clear error instead of the reference's NameError.
+  callback_on_step_end may return `latents` and `prompt_embeds` (:1651-1659); a replaced context re-hoists the text K / V of the
+      cross-attention blocks and re-captures the step.  `negative_prompt_embeds` is accepted and, as in the reference (the name
+      is never read after the CFG concat at :1465), has no effect.
   Q3  preview latents are copied to the host only when `save_preview_row=True`.
   Q5  `multistep_restore=True` raises NotImplementedError (unusable with the shipped scheduler).
   Q8/Q13  Resampler / embeddings hoisted out of the step.
@@ -241,6 +245,10 @@ class InstantIRPipeline:
             self._unet = HipUNet(self.cfg, self._unet_sd, self.device)
         if self._active_adapter is not None:
             key = (self._active_adapter, float(lora_mult))
+            if key not in self._prev_nets and float(lora_mult) != 1.0:
+                # a merged copy is a whole UNet (~5 GB at SDXL size): keep ONE non-default scale per adapter, evict the previous
+                for k_old in [k for k in self._prev_nets if k[0] == self._active_adapter and k[1] != 1.0 and len(k) == 2]:
+                    del self._prev_nets[k_old]
             if key not in self._prev_nets:
                 if self._lora is None:
                     raise RuntimeError(f"LoRA adapter {self._active_adapter!r}: the host copy was released; call prepare_previewers again")
@@ -375,10 +383,11 @@ class InstantIRPipeline:
         if self._lora is None:
             raise RuntimeError("restore_single_step needs the previewer LoRA: call prepare_previewers(...)")
         if fp8:
-            if getattr(self, "_unet_prev8", None) is None:
-                self._unet_prev8 = HipUNet(self.cfg, self._unet_sd, self.device, lora=self._lora, lora_scaling=self._lora_scaling,
-                                           fp8_linear=True)
-            net = self._unet_prev8
+            key8 = (self._active_adapter, 1.0, "fp8")            # one fp8 copy per adapter: `set_adapter` must not leave a stale one
+            if key8 not in self._prev_nets:
+                self._prev_nets[key8] = HipUNet(self.cfg, self._unet_sd, self.device, lora=self._lora, lora_scaling=self._lora_scaling,
+                                                fp8_linear=True)
+            net = self._unet_prev8 = self._prev_nets[key8]
         else:
             self._build()
             net = self._unet_prev
@@ -474,6 +483,9 @@ class InstantIRPipeline:
         n_img = 1 if hasattr(image, "size") and not torch.is_tensor(image) and not isinstance(image, (list, tuple)) else len(image)
         assert pb == n_img or n_img == 1                                          # :1310-1315
         if ip_adapter_image is None and ip_adapter_image_embeds is None:           # :1278-1279 (see Q15 in the header)
+            if torch.is_tensor(image) and image.dim() == 4 and image.shape[1] == 4:
+                raise ValueError("`image` is an LQ latent (B,4,h,w): it cannot stand in for `ip_adapter_image` (the image encoder takes "
+                                 "pixels); pass `ip_adapter_image` or `ip_adapter_image_embeds`")
             ip_adapter_image = image
         if nipp > 1:            # diffusers encode_prompt: embeds.repeat(1, n, 1).view(bs * n, ...) == repeat_interleave
             prompt_embeds = prompt_embeds.repeat_interleave(nipp, 0)
@@ -623,9 +635,30 @@ class InstantIRPipeline:
                 prev_l2 = (pv - loop.previewer_mean).pow(2).sum(dim=(1, 2, 3))
                 loop.previewer_mean = pv
                 preview_factor = (pred_x0_l2 / prev_l2).cpu()
-            if callback_on_step_end is not None:
-                cb = callback_on_step_end(self, i, t, {"latents": x})
+            if callback_on_step_end is not None:                                   # :1646-1659
+                cb_in = {"latents": x}
+                for name in (callback_on_step_end_tensor_inputs or []):            # (`prompt_embeds` here is the CFG-concatenated context)
+                    if name == "prompt_embeds":
+                        cb_in[name] = ctx
+                    elif name == "negative_prompt_embeds":
+                        cb_in[name] = negative_prompt_embeds
+                cb = callback_on_step_end(self, i, t, cb_in)
                 x = cb.pop("latents", x)
+                new_ctx = cb.pop("prompt_embeds", None)
+                cb.pop("negative_prompt_embeds", None)       # the reference rebinds a name it never reads again (:1465, :1655): no effect
+                if new_ctx is not None and new_ctx is not ctx:
+                    # the text K / V^T of all 70 cross-attention blocks are hoisted per call: a replaced context means hoisting
+                    # again (and a new captured step), after which the loop continues on the same latents
+                    if tuple(new_ctx.shape) != tuple(ctx.shape):
+                        raise ValueError(f"callback_on_step_end returned prompt_embeds of shape {tuple(new_ctx.shape)}, expected {tuple(ctx.shape)}")
+                    ctx = new_ctx
+                    st = self._unet.prepare(ctx, pooled, time_ids, self._unet.resampler(img), Hl, Wl)
+                    if self._unet_prev is not None:
+                        st_prev = self._unet_prev.prepare(ctx, pooled, time_ids, self._unet_prev.resampler(img), Hl, Wl)
+                    mean_keep = loop.previewer_mean
+                    loop = _DenoiseLoop(self, B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler,
+                                        guidance_rescale=guidance_rescale)
+                    loop.previewer_mean = mean_keep
         latents_out = x
         if output_type == "latent":
             image_out = latents_out

@@ -31,8 +31,9 @@ def _worker(rank, world, port, q):
     same = all(torch.equal(sd[k], want[k]) for k in want)
     lo, hi = parallel.shard_range(9, r, w)
     mx = parallel.max_over_ranks(1.0 + r, dev)
+    per_rank = parallel.gather_floats(10.0 + r, dev)       # bench.py's ms_per_step_by_rank
     parallel.barrier()
-    q.put((r, same, (lo, hi), mx))
+    q.put((r, same and per_rank == [10.0, 11.0], (lo, hi), mx))
     dist.destroy_process_group()
 
 

@@ -251,6 +251,34 @@ def test_denoising_end_custom_timesteps_and_callback(env):
     assert p >= BAR, p
 
 
+def test_callback_may_replace_prompt_embeds(env):
+    """`callback_on_step_end` (:1646-1659) is handed the tensors it names and may hand back `prompt_embeds` (the CFG-concatenated
+    context): unchanged -> bit-identical to a run without callback; replaced -> the text K / V of the cross-attention blocks are
+    hoisted again and the remaining steps run on the new context (the result moves, stays finite); a wrong shape is refused."""
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    kw = dict(num_inference_steps=4, guidance_scale=5.0)
+    base = _call(pipe, inp, **kw)
+    seen = []
+
+    def same(p_, i, t, k):
+        seen.append(tuple(k["prompt_embeds"].shape))
+        return {"latents": k["latents"], "prompt_embeds": k["prompt_embeds"], "negative_prompt_embeds": k.get("negative_prompt_embeds")}
+
+    got = _call(pipe, inp, callback_on_step_end=same, callback_on_step_end_tensor_inputs=["latents", "prompt_embeds", "negative_prompt_embeds"], **kw)
+    assert torch.equal(got, base) and seen[0] == (2 * inp["B"], cfg.text_len, cfg.cross_attention_dim)
+
+    def swap(p_, i, t, k):
+        return {"prompt_embeds": (k["prompt_embeds"] * 0.25) if i == 1 else k["prompt_embeds"]}
+
+    moved = _call(pipe, inp, callback_on_step_end=swap, callback_on_step_end_tensor_inputs=["prompt_embeds"], **kw)
+    assert torch.isfinite(moved).all() and not torch.equal(moved, base)
+    with pytest.raises(ValueError):
+        _call(pipe, inp, callback_on_step_end=lambda p_, i, t, k: {"prompt_embeds": k["prompt_embeds"][:1]},
+              callback_on_step_end_tensor_inputs=["prompt_embeds"], **kw)
+
+
 def test_num_images_per_prompt(env):
     """num_images_per_prompt = 2 with ONE prompt / image: embeds repeat per prompt copy (diffusers encode_prompt), the LQ
     latent repeats over the batch (prepare_image :919-925), IP embeds repeat on dim 0 (:709-722).  Rows are independent, so
@@ -280,7 +308,17 @@ def test_ip_adapter_image_defaults_to_image_and_preview_row(env):
     lcm = LCMSingleStepScheduler.from_config(pipe.scheduler.config)
     base = dict(image=inp["lq"], prompt_embeds=inp["pe"], pooled_prompt_embeds=inp["pooled"], output_type="latent",
                 negative_prompt_embeds=inp["npe"], negative_pooled_prompt_embeds=inp["npooled"], previewer_scheduler=lcm, init_noise=inp["init_noise"], num_inference_steps=3, guidance_scale=5.0)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                        # an LQ *latent* cannot stand in for the image encoder's input: said up front
+        pipe(**base)
+
+    class _Vae:                                            # pixel-space `image`: the VAE stand-in returns the fixture's LQ latent
+        def encode_to_latent(self, image, eps=None, generator=None):
+            assert image.shape[1] == 3 and image.min() >= -1.0 and image.max() <= 1.0
+            return inp["lq"]
+
+    pipe.vae = _Vae()
+    base["image"] = torch.rand(inp["lq"].shape[0], 3, inp["lq"].shape[2] * 8, inp["lq"].shape[3] * 8, generator=torch.Generator().manual_seed(3))
+    with pytest.raises(NotImplementedError):               # default ip_adapter_image = image, but no image encoder attached
         pipe(**base)
 
     class _Enc:                                            # stands in for encoders.HipDinov2: (features, zero-image features)
@@ -297,7 +335,7 @@ def test_ip_adapter_image_defaults_to_image_and_preview_row(env):
 def test_single_step_previewer_restoration_fp8(env):
     """BASELINE configs[4]: the same single LCM step with the transformer linears on fp8-E4M3 weights.  Its tolerance is its
     own (8-bit operands with 3 mantissa bits; the reference has no fp8 path to compare with): asserted against the fp32
-    oracle at >= 20 dB and against the fp16 HIP path at >= 20 dB; measured values go to gpurun_out/psnr.log."""
+    oracle at >= 40 dB (measured 46.3) and against the fp16 HIP path at >= 40 dB; measured values go to gpurun_out/psnr.log."""
     from instantir_amd.schedulers import DDPMScheduler
     from oracle import nets, sched
     cfg, sd, sda, lora, inp = env
@@ -316,7 +354,7 @@ def test_single_step_previewer_restoration_fp8(env):
     ip = nets.image_projection(P, [feats], cfg.resampler, L)[0]
     want = sched.lcm_step(acp, nets.unet_forward(P, cfg, x, 999, inp["pe"], inp["pooled"], tid, ip, lora=L), 999, x)
     p_oracle, p_16 = psnr(got8, want), psnr(got8, got16)
-    assert torch.isfinite(got8).all() and p_oracle >= 20 and p_16 >= 20, (p_oracle, p_16)
+    assert torch.isfinite(got8).all() and p_oracle >= 40 and p_16 >= 40, (p_oracle, p_16)
     assert not torch.equal(got8, got16)                      # the fp8 weight set is really in use
 
 

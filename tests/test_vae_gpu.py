@@ -2,8 +2,9 @@
 kernels added for it (row softmax fp16 and fp32->16-bit, bottom/right-padded stride-2 conv, bf16 GEMM / conv / GroupNorm).
 
 Tolerances (the reference runs its VAE in fp32, pipelines/sdxl_instantir.py:984-1001,1668-1674; the oracle is fp32):
-  bf16 build (default): 8 significant bits per stored activation -> pixel PSNR >= 33 dB asserted (measured values are logged
-  to gpurun_out/psnr.log); fp16 build: >= 40 dB.  The 8-bit image the pipeline returns quantises at 58.9 dB."""
+  bf16 build (default): 8 significant bits per stored activation -> pixel PSNR >= 47 dB asserted (measured 53.4-58.6 dB, logged
+  to gpurun_out/psnr.log); fp16 build: >= 65 dB (measured 71.8-76.4).  The bars sit ~6 dB under what is measured, so a
+  regression of one bit of precision fails.  The 8-bit image the pipeline returns quantises at 58.9 dB."""
 import math
 
 import pytest
@@ -22,7 +23,7 @@ def psnr(got, want):
     return v
 
 
-BAR = {torch.bfloat16: 33.0, torch.float16: 40.0}
+BAR = {torch.bfloat16: 47.0, torch.float16: 65.0}
 
 
 @pytest.fixture(scope="module")
@@ -194,7 +195,7 @@ def test_pipeline_pixels_in_pixels_out(vae_env, dev):
     want = (OV.decode(PV, vc, lat / vc.scaling_factor) / 2 + 0.5).clamp(0, 1)
     assert got.shape == (B, 3, 128, 128)
     p = psnr(got, want)
-    assert p > BAR[hv.dtype] - 5, p            # encode -> 3 denoising steps -> decode: the three stages' errors add
+    assert p > BAR[hv.dtype] - (0 if hv.dtype == torch.bfloat16 else 8), p      # encode -> 3 denoising steps -> decode: the stages' errors add (measured 52.6 bf16, 62.2 fp16)
 
 
 def test_vae_tiled_decode_matches_oracle(vae_env):
@@ -259,7 +260,7 @@ def test_vae_activation_overflow(dev):
     assert torch.isfinite(want).all()
     got = HipVAE(vc, sd, dev, dtype=torch.bfloat16).decode(z).cpu()
     p = psnr(got, want)
-    assert torch.isfinite(got).all() and p > 30, p
+    assert torch.isfinite(got).all() and p > 50, p          # measured 58.2
     with pytest.raises(FloatingPointError):
         HipVAE(vc, sd, dev, dtype=torch.float16).decode_latent(z * vc.scaling_factor, "pt")
 
