@@ -36,8 +36,24 @@ template <> struct ET<bf16> {
 
 // 16-byte async global -> LDS copy (global_load_lds_dwordx4).  LDS destination is
 // wave-uniform base + lane*16; the global source address is per lane.
+//
+// Round 3: issued through inline asm, invisible to hipcc.  With the builtin in a loop, hipcc's wait insertion (ROCm 7.2) treats
+// the pending LDS-DMA as an LDS event of unknown order and degrades EVERY `s_waitcnt lgkmcnt(N)` in that loop to `lgkmcnt(0)`:
+// fragment reads issued a sub-step ahead (to run under the MFMAs) were waited for at once, one exposed LDS round trip per MFMA
+// group in every GEMM / conv / attention main loop (tools/probes: the same loop gets `lgkmcnt(10)/(9)/(8)/(7)` without the
+// builtin, one `lgkmcnt(0)` with it).  The kernels order the DMA themselves anyway -- counted `s_waitcnt vmcnt(N)` + barrier in
+// asm before any read of a staged buffer -- so nothing relied on the compiler knowing about it.  M0 (the LDS destination base)
+// is written and restored inside the statement (cdna_hip_programming.md 5.7: M0 is compiler-reserved).
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+#ifdef IIR_GLDS_BUILTIN
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+#else
+    // (the low 32 bits of a generic pointer into LDS are the LDS byte address: no address-space cast with its null check)
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#endif
 }
 
 // x * sigmoid(x) with one v_exp and one v_rcp (1 ulp) instead of the IEEE division sequence: the GroupNorm + SiLU pass

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
             } else {
                 for (int t = 0; t < 8; ++t) o[t] = (E)((float)v[t] * g.out_scale);
             }
-            *(E8*)(g.C + m * g.ldc + no_tile + cc * 8) = o;
+            iir::store16(g.C, (m * g.ldc + no_tile + cc * 8) * 2, o, g.st_wt != 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA touches must land before the LDS is released

@@ -28,6 +28,15 @@ namespace {
 using iir::Geo;
 
 constexpr int BK = 64;   // halfs per K tile = one 128-byte LDS row
+// Issue-order pin (round 3).  The K loop is written as  [fragment reads of the NEXT half step] [MFMAs of the CURRENT half step],
+// so that the LDS latency runs under the matrix instructions.  hipcc's scheduler sank the reads below the MFMAs and then waited
+// `lgkmcnt(0)` right behind them -- one exposed LDS round trip (~200 cycles with four waves reading and the LDS-DMA writing) per
+// half step, with one wave per SIMD nothing else to cover it.  A scheduling barrier after each read group keeps the source order.
+#ifndef IIR_NO_PIN
+#define IIR_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define IIR_PIN() ((void)0)
+#endif
 constexpr int PF_TOUCHES = 4;   // prefetch touches per lane per launch (x 128 B x threads = up to 128-256 KiB per workgroup)
 #define IIR_DEFAULT_STAGES 2
 #ifndef IIR_T1_MIN
@@ -301,6 +310,10 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         for (int j = 0; j < NI; ++j) bf[j] = *(const BF*)(bs + b_off[s] + j * 16 * (W8 ? 64 : 128));
     };
     auto mma = [&](const E8 (&af)[MI], const BF (&bf)[NI]) {
+#ifdef IIR_DBG_NO_MFMA       // (trigger bisection of DESIGN.md 5.8: same loads, barriers and LDS reads, no matrix instructions; results are wrong)
+        for (int i = 0; i < MI; ++i) for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(af[i]), "v"(bf[j]));
+        return;
+#endif
         if constexpr (!W8) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -347,27 +360,44 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     };
     E8 a0[MI], a1[MI];
     BF b0[NI], b1[NI];
+    // Loop form (round 3).  Per K tile the instruction order is unchanged -- [reads of half step 1][MFMAs of half step 0]
+    // [barrier: next tile landed][reads of the next tile's half step 0][MFMAs of half step 1] -- but the loop now BEGINS at the
+    // barrier, and the barrier's `lgkmcnt(0)` is a compiler-visible builtin.  With fragment reads pending across the back edge
+    // (the first form) hipcc's wait insertion fell back to `lgkmcnt(0)` in front of every MFMA group, i.e. it also waited for the
+    // reads issued one instruction earlier for the NEXT group: one exposed LDS round trip per half step.  With nothing pending at
+    // the loop head the same reads get counted waits (`lgkmcnt(7)`): the prefetched group stays in flight under the MFMAs.
+    auto admit2 = [&](int tiles_after) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): every fragment read of the finished tile has returned
+        if (ST >= 5 && tiles_after >= 3) wait_vm_and_barrier<(ST >= 5 ? 3 * LOADS : 0)>();
+        else if (ST >= 4 && tiles_after >= 2) wait_vm_and_barrier<(ST >= 4 ? 2 * LOADS : 0)>();
+        else if (ST >= 3 && tiles_after >= 1) wait_vm_and_barrier<(ST >= 3 ? LOADS : 0)>();
+        else wait_vm_and_barrier<0>();
+    };
     if constexpr (!LW) {
         {
             const int rem = nk - 1 - kt0;
             admit(rem < ST - 2 ? rem : ST - 2);
             if (kt0 + ST - 1 < nk) stage(kt0 + ST - 1, ST - 1);
             frags(0, 0, a0, b0);
+            IIR_PIN();
+            frags(0, 1, a1, b1);
+            IIR_PIN();
+            mma(a0, b0);
         }
         int cur = 0;
-        for (int kt = kt0; kt + 1 < nk; ++kt) {                 // (last tile peeled: no conditional definition of the loop-carried
-            frags(cur, 1, a1, b1);                              //  fragment registers, which cost 80 v_mov per iteration)
-            mma(a0, b0);
-            const int rem = nk - 2 - kt;                        // tiles that exist after kt+1
-            admit(rem < ST - 2 ? rem : ST - 2);
-            if (kt + ST < nk) stage(kt + ST, cur);              // tile kt's buffer is free: every wave finished reading it
+        for (int kt = kt0 + 1; kt < nk; ++kt) {                 // kt = the tile this iteration admits and starts
+            const int rem = nk - 1 - kt;                        // tiles that exist after kt
+            admit2(rem < ST - 2 ? rem : ST - 2);
+            if (kt - 1 + ST < nk) stage(kt - 1 + ST, cur);      // tile kt-1's buffer is free: every wave finished reading it
             cur = cur + 1 == ST ? 0 : cur + 1;
             frags(cur, 0, a0, b0);
-            mma(a1, b1);
+            IIR_PIN();
+            mma(a1, b1);                                        // tile kt-1, half step 1
+            frags(cur, 1, a1, b1);
+            IIR_PIN();
+            mma(a0, b0);                                        // tile kt, half step 0
         }
         preload_cols();
-        frags(cur, 1, a1, b1);
-        mma(a0, b0);
         mma(a1, b1);
     } else if (loader) {
         // loader waves: same barriers, same counted waits, no LDS reads and no MFMAs
@@ -387,18 +417,22 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         // compute waves: they issue no vector-memory operation in the loop, so the vmcnt part of `admit` never waits
         admit(0);
         frags(0, 0, a0, b0);
+        IIR_PIN();
+        frags(0, 1, a1, b1);
+        IIR_PIN();
+        mma(a0, b0);
         int cur = 0;
-        for (int kt = kt0; kt + 1 < nk; ++kt) {
-            frags(cur, 1, a1, b1);
-            mma(a0, b0);
-            admit(0);
+        for (int kt = kt0 + 1; kt < nk; ++kt) {
+            admit2(0);
             cur = cur + 1 == ST ? 0 : cur + 1;
             frags(cur, 0, a0, b0);
+            IIR_PIN();
             mma(a1, b1);
+            frags(cur, 1, a1, b1);
+            IIR_PIN();
+            mma(a0, b0);
         }
         preload_cols();
-        frags(cur, 1, a1, b1);
-        mma(a0, b0);
         mma(a1, b1);
     }
 
@@ -548,6 +582,9 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     // for the launches that follow (see iir_gemm_desc.prefetch: 4-byte LDS-DMA touches, clamped into the range; no VGPR
     // destination, the data lands in a scratch KiB behind the ring and is never read), then the stores.
     auto touch_next_weights = [&]() {
+#ifdef IIR_DBG_NO_TOUCH      // (trigger bisection of DESIGN.md 5.8: build without the prefetch touches)
+        return;
+#endif
         const int per = (g.pf_lines + (int)gridDim.x - 1) / (int)gridDim.x;
         const long l0 = (long)blockIdx.x * per, last = g.pf_lines - 1;
         char* scratch = smem + RING_BYTES + wave_all * 256;
@@ -616,7 +653,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
             for (int k = 0; k < CH; ++k) {
                 const int c = tid + k * NT, r = c / CPR, cc = c - r * CPR;
                 if (TOTAL % NT != 0 && c >= TOTAL) break;
-                *(E8*)(g.C + (long)(m0 + r) * g.ldc + no_tile + cc * 8) = o[k];
+                iir::store16(g.C, ((long)(m0 + r) * g.ldc + no_tile + cc * 8) * 2, o[k], g.st_wt != 0);
             }
             if constexpr (LN_OUT_FITS) {
                 if (g.ln_out) {
@@ -686,7 +723,8 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 256 * WAVES_M * 2 * (LW ? 2 : 1) + BM * 8;   // ring (reused as the output tile) + prefetch scratch (256 B per wave) + LayerNorm row statistics
+    static const size_t dbg_pad = getenv("IIR_DBG_LDS_PAD") ? (size_t)atoi(getenv("IIR_DBG_LDS_PAD")) : 0;     // (5.8 bisection: force one workgroup per CU)
+    const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 256 * WAVES_M * 2 * (LW ? 2 : 1) + BM * 8 + dbg_pad;   // ring (reused as the output tile) + prefetch scratch (256 B per wave) + LayerNorm row statistics
     if (g.ln_out) {         // producer of LayerNorm partials: whole tiles, 16-byte rows, plain epilogue (see the kernel's fast write-out path)
         constexpr bool fits = (BM * (2 * BN + 32) + 15) / 16 * 16 + BM * (BN / 8) * 8 <= ST * (BM * 128 + (W8 ? BN * 64 : BN * 128));
         if (!fits || conv || g.epi != IIR_EPI_PLAIN || g.c_f32 || g.Ct || g.splitk == 2 || g.M % BM || g.N % BN || !g.c_vec || (g.res && !g.r_vec))
@@ -887,6 +925,8 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
 
 // no prefetch requested: the (unconditional) touches re-read the first line of this launch's own weights
 void finish_geo(Geo& g) {
+    static const int wt = getenv("IIR_ST_WT") ? atoi(getenv("IIR_ST_WT")) : 1;      // A/B switch; default on (step 60.39 -> 60.22 ms, same box)
+    g.st_wt = wt && ((long)g.M * g.ldc * 2 < (1L << 31));      // 32-bit buffer offsets
     if (g.pf_lines <= 0) { g.pf = (const char*)g.W; g.pf_lines = 1; }
     g.c_vec = (g.ldc % 8 == 0) && ((uintptr_t)g.C % 16 == 0);
     g.r_vec = g.res && (g.ldr % 8 == 0) && ((uintptr_t)g.res % 16 == 0);

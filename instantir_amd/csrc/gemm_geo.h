@@ -4,6 +4,23 @@
 
 namespace iir {
 
+typedef unsigned iir_u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte store of an output row chunk.  `wt`: write-through (`buffer_store_dwordx4 ... sc1`).  A GEMM leaves MBs of dirty lines
+// in the eight L2s; the kernel's end-of-dispatch release has to write them back before the next (dependent) launch can start --
+// time after the last workgroup has finished (MI355X_MICROARCH.md, row publish-large: 8.2 vs 3.0 us for 2 MB per XCD).  The
+// consumer is another launch on other XCDs anyway (it reads through the Infinity Cache), so nothing is lost by not keeping the
+// lines.
+template <typename V>
+__device__ __forceinline__ void store16(void* base, long byte_off, const V& v, bool wt) {
+    static_assert(sizeof(V) == 16, "16-byte chunk");
+    if (wt) {
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(iir_u32x4, v), r, (int)byte_off, 0, 16);
+    } else {
+        *(V*)((char*)base + byte_off) = v;
+    }
+}
+
 struct Geo {   // per-launch constants shared by GEMM and CONV paths
     const f16* A; long lda;
     const f16* W;
@@ -35,6 +52,7 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     const float* ln_in;             // consumer: those partials; A holds the RAW rows, W has gamma folded in
     int ln_parts, ln_part_cols;     //   partial count per row and the columns each one covers
     float ln_eps;
+    int st_wt;                      // write the output through to memory (sc1 stores): nothing is left dirty in the L2s for the end-of-kernel write-back
     const float* ln_colsum;         //   s[n] = sum_k W[n][k] (fp32): y = rstd * (x . w_n) - rstd * mean * s[n] (+ bias, which carries W . beta)
 };
 

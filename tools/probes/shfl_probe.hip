@@ -164,6 +164,42 @@ int main(int argc, char** argv) {
     iir_gemm_desc gd; memset(&gd, 0, sizeof gd);
     gd.A = ga; gd.lda = 1280; gd.W = gw; gd.C = gc; gd.ldc = 2560; gd.M = 4096; gd.N = 2560; gd.K = 1280;
     std::vector<float> first(RG * 2), cur(RG * 2);
+    if (getenv("PROBE_CUMASK")) {
+        // ONE discriminating experiment.  The failing form (V0) beside its trigger (the library's 64x160 GEMM),
+        // with the two streams (a) unrestricted, (b) on DISJOINT halves of the chip's CUs, (c) on the SAME half.  Clean when disjoint
+        // => the trigger disturbs CU-local state of a co-resident wave; failing when disjoint => the memory side.
+        // The reference result is taken with NO neighbour; every launch beside the neighbour is compared with it.
+        uint32_t lo[8], hi[8], all[8];
+        for (int i = 0; i < 8; ++i) { lo[i] = i < 4 ? 0xFFFFFFFFu : 0u; hi[i] = i < 4 ? 0u : 0xFFFFFFFFu; all[i] = 0xFFFFFFFFu; }
+        struct Pl { const char* name; const uint32_t* victim; const uint32_t* trigger; } pls[] = {
+            {"both streams on all CUs", all, all}, {"victim CUs 0-127, trigger CUs 128-255 (disjoint)", lo, hi},
+            {"victim and trigger both on CUs 0-127", lo, lo}, {"victim CUs 128-255, trigger CUs 0-127 (disjoint)", hi, lo}};
+        hipLaunchKernelGGL(fin<0>, dim3((RG + 3) / 4), dim3(256), 0, 0, part, nslab, G, 320.f, stat, RG);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(first.data(), stat, RG * 2 * 4, hipMemcpyDeviceToHost));
+        for (auto& pl : pls) {
+            hipStream_t sv, st;
+            CK(hipExtStreamCreateWithCUMask(&sv, 8, pl.victim));
+            CK(hipExtStreamCreateWithCUMask(&st, 8, pl.trigger));
+            for (int with = 1; with >= 0; --with) {
+                int nd = 0; float maxd = 0.f;
+                for (int it = 0; it < REP; ++it) {
+                    for (int k = 0; k < 3 && with; ++k) { gd.tile = 25; if (gemm(&gd, st)) { printf("gemm launch failed\n"); return 1; } }
+                    CK(hipMemsetAsync(stat, 0, RG * 2 * 4, sv));
+                    hipLaunchKernelGGL(fin<0>, dim3((RG + 3) / 4), dim3(256), 0, sv, part, nslab, G, 320.f, stat, RG);
+                    CK(hipDeviceSynchronize());
+                    CK(hipMemcpy(cur.data(), stat, RG * 2 * 4, hipMemcpyDeviceToHost));
+                    bool d = false;
+                    for (int i = 0; i < RG * 2; ++i) if (cur[i] != first[i]) { d = true; const float e = fabsf(cur[i] - first[i]); if (e > maxd) maxd = e; }
+                    nd += d;
+                }
+                printf("%-52s %s: %2d of %d launches differ from the quiet-chip result (max |diff| %.3g)\n", pl.name,
+                       with ? "beside the 64x160 GEMM" : "alone                 ", nd, REP, maxd);
+            }
+            CK(hipStreamDestroy(sv)); CK(hipStreamDestroy(st));
+        }
+        return 0;
+    }
     // noise = (kind, tile): which kernel of the library keeps the other stream busy
     struct Nz { const char* name; int kind, tile; } nzs[] = {{"none", 0, 0}, {"gemm 128x160", 1, 24}, {"gemm 64x160", 1, 25},
                                                              {"spin 32 vgpr", 4, 32}, {"spin 96 vgpr", 4, 96}, {"spin 160 vgpr", 4, 160}};
