@@ -85,6 +85,9 @@ int iir_gemm_f16(const iir_gemm_desc* d, void* stream);
 int iir_gemm_ln_parts(int32_t M, int32_t N, int32_t K);
 /* the tile `tile = 0` resolves to for an (M, N, K) problem (paired != 0 for GEGLU / SFT epilogues) */
 int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired);
+/* The tile / kernel iir_gemm_f16(d) resolves to, without launching (91: the 8-wave 256x320 kernel of csrc/gemm8.hip, used for the
+ * GEGLU projections of module/min_sdxl.py:502-528 when its tiles fill the chip); -1 for an invalid descriptor. */
+int iir_gemm_resolve_tile(const iir_gemm_desc* d);
 /* bytes of split-K workspace an (M, N) problem can use (0: the split form does not apply to it) */
 int64_t iir_gemm_splitk_workspace_bytes(int32_t M, int32_t N);
 /* 1 if a tile = 0 launch of this problem with a workspace of ws_bytes takes the two-slice split-K form (128x160 tile) */

@@ -851,6 +851,11 @@ bool uses_splitk(int M, int N, int K, long ws_bytes) {
     return K >= one_per_cu_min_k() && (K / BK) % 2 == 0 && need > 0 && ws_bytes >= need;
 }
 
+bool gemm8_auto(const Geo& g, bool conv) {
+    static const bool g8_on = !(getenv("IIR_G8") && atoi(getenv("IIR_G8")) == 0);
+    return g8_on && !conv && g.K >= 640 && (long)(g.M / 256) * (g.N / 320) >= 256 && iir::gemm8_covers(g, 320);
+}
+
 int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // Two-slice split-K, taken only when the caller hands over a workspace: two 128x160 workgroups per tile each take half of
     // K and the last one to finish reduces (see the kernel).  Meant for long-K problems too small to fill the chip with
@@ -866,9 +871,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // tile: 0 = auto; t in {1: 128x128, 2: 128x64, 3: 64x64, 4: 128x160, 5: 64x160}; t + 10*stages selects the ring depth.
     // large-N linears whose 256 x 320 tiles fill the chip (the GEGLU projections): the 8-wave two-tile-deep kernel of
     // gemm8.hip (142 FLOP per staged byte against 71 for two 128x160 workgroups per CU).  IIR_G8=0 switches it off (A/B).
-    static const bool g8_on = !(getenv("IIR_G8") && atoi(getenv("IIR_G8")) == 0);
-    if (tile == 0 && g8_on && !conv && g.K >= 640 && (long)(g.M / 256) * (g.N / 320) >= 256 && iir::gemm8_covers(g, 320))
-        return iir::gemm8_launch(g, 320, stream);
+    if (tile == 0 && gemm8_auto(g, conv)) return iir::gemm8_launch(g, 320, stream);
     if (tile == 91 || tile == 92) return conv ? IIR_EINVAL : iir::gemm8_launch(g, tile == 91 ? 320 : 256, stream);
     if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
     if (tile < 10) {
@@ -950,15 +953,33 @@ extern "C" int iir_gemm_ln_parts(int32_t M, int32_t N, int32_t K) {
     return N / bn;
 }
 
+static int fill_gemm_geo(const iir_gemm_desc* d, Geo& g);
+
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     (void)hipGetLastError();
+    Geo g{};
+    const int rc = fill_gemm_geo(d, g);
+    if (rc != IIR_OK) return rc;
+    return dispatch(g, false, d->tile, (hipStream_t)stream);
+}
+
+// Which kernel / tile `iir_gemm_f16(d)` resolves to, without launching: 91 = the 8-wave 256x320 kernel (gemm8.hip), otherwise the
+// 4-wave tile id of `iir_gemm_pick_tile` (or d->tile when the caller forces one).  Used to NAME launches (bench.py roofline classes).
+extern "C" int iir_gemm_resolve_tile(const iir_gemm_desc* d) {
+    Geo g{};
+    if (fill_gemm_geo(d, g) != IIR_OK) return -1;
+    if (d->tile != 0) return d->tile;
+    if (gemm8_auto(g, false)) return 91;
+    return pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
+}
+
+static int fill_gemm_geo(const iir_gemm_desc* d, Geo& g) {
     if (!d || !d->A || !d->W || !d->C) return IIR_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % BK) return IIR_EINVAL;
     if (d->N % 4 || d->lda % 8 || d->ldc % 4) return IIR_EINVAL;
     if (d->epi != IIR_EPI_PLAIN && (d->N % 16)) return IIR_EINVAL;
     if (d->epi == IIR_EPI_SFT && !d->res) return IIR_EINVAL;
     if (d->rowbias && d->rows_per_rb <= 0) return IIR_EINVAL;
-    Geo g{};
     g.A = (const f16*)d->A; g.lda = d->lda; g.W = (const f16*)d->W; g.C = (f16*)d->C; g.ldc = d->ldc;
     g.M = d->M; g.N = d->N; g.K = d->K;
     g.bias = (const f16*)d->bias; g.rowbias = (const f16*)d->rowbias; g.ldrb = d->ldrb; g.rows_per_rb = d->rows_per_rb;
@@ -995,7 +1016,7 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
         g.ln_in = (const float*)d->ln_stats_in; g.ln_colsum = (const float*)d->ln_colsum;
         g.ln_parts = d->ln_parts; g.ln_part_cols = d->ln_part_cols; g.ln_eps = d->ln_eps;
     }
-    return dispatch(g, false, d->tile, (hipStream_t)stream);
+    return IIR_OK;
 }
 
 extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {

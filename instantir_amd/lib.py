@@ -96,6 +96,7 @@ SIGNATURES = {
     "iir_gemm_splitk_workspace_bytes": (C.c_int64, [_I32, _I32]),
     "iir_gemm_uses_splitk": (C.c_int, [_I32, _I32, _I32, _I64]),
     "iir_gemm_pick_tile": (C.c_int, [_I32, _I32, _I32, _I32]),
+    "iir_gemm_resolve_tile": (C.c_int, [_P]),
     "iir_gemm_tile_bn": (C.c_int, [_I32]),
     "iir_gemm_ln_parts": (C.c_int, [_I32, _I32, _I32]),
     "iir_conv2d_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), _P]),

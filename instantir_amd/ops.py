@@ -234,7 +234,11 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
             raise ValueError("out_t must hold (N - tr_from, M)")
         d.Ct, d.ldct, d.tr_from = ct.data_ptr(), ct.stride(0), tr_from
     No = N // 2 if epi != EPI_PLAIN else N
-    with _Timed("gemm_kernel<%s,%s>" % (_TILE_NAMES[tile % 10], "gemm" if wscale is None else "gemm-w8"), 2.0 * M * N * K,
+    if PROFILER is not None and d.tile == 0 and L.load().iir_gemm_resolve_tile(C.byref(d)) == 91:
+        cls = "gemm8_kernel<256x320,gemm>"             # the 8-wave kernel of csrc/gemm8.hip
+    else:
+        cls = "gemm_kernel<%s,%s>" % (_TILE_NAMES[tile % 10], "gemm" if wscale is None else "gemm-w8")
+    with _Timed(cls, 2.0 * M * N * K,
                 2.0 * (M * K + N * K * (1.0 if wscale is None else 0.5) + M * No + (M * No if res is not None else 0))):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out

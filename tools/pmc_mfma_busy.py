@@ -7,6 +7,7 @@ def cls_of(name):
     if m: return "gemm_kernel<%sx%s,%s>" % (m.group(1), m.group(2), "conv" if m.group(4) == "true" else "gemm")
     m = re.search(r"gemm_kernelI(?:DF16_|DF16b)?Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)", name)
     if m: return "gemm_kernel<%sx%s,%s>" % (m.group(1), m.group(2), "conv" if m.group(4) == "1" else "gemm")
+    if "gemm8_kernel" in name: return "gemm8_kernel<256x320,gemm>"
     if "attn_kernel" in name: return "attn_kernel"
     return None
 rows = collections.defaultdict(dict)

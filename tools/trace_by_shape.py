@@ -10,6 +10,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         m = re.search(r"gemm_kernel<([^>]*)>", name)
         short = ("gemm<" + m.group(1).replace(" ", "") + ">") if m else re.sub(r"\(.*", "", name)[-50:]
         if "attn_kernel" in name: short = "attn_kernel2" if "kernel2" in name else "attn_kernel"
+        if "gemm8_kernel" in name: short = "gemm8<256x%s>" % ("320" if "Li320E" in name or "<320" in name else "256")
         m2 = re.search(r"gemm_kernelI(DF16_|DF16b)?Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d)", name)
         if m2: short = f"gemm<{'bf16,' if m2.group(1) == 'DF16b' else ''}{m2.group(2)}x{m2.group(3)},st{m2.group(4)},{'conv' if m2.group(5) == '1' else 'gemm'},w{m2.group(6)}>"
         key = (short, r.get("Grid_Size_X", r.get("Grid_Size", "")))
