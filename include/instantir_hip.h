@@ -74,6 +74,10 @@ typedef struct iir_gemm_desc {
     int32_t ln_parts, ln_part_cols;/*   bias must carry W . beta; the kernel merges the `ln_parts` partials of each row (each over   */
     float ln_eps;                  /*   `ln_part_cols` columns; parts x cols == K) to (mean, rstd) and forms                         */
     const void* ln_colsum;         /*   C = epi(rstd * (A . W^T) - rstd * mean * ln_colsum[n] + bias ...), ln_colsum[n] = sum_k W[n][k] (fp32) */
+    /* GroupNorm statistics from the launch that produces the GroupNorm's input (nn.Conv2d / proj_out -> nn.GroupNorm pairs,          */
+    /* module/min_sdxl.py:242-283,565-595): no separate statistics pass over the tensor                                               */
+    void* gn_stats_out;            /* optional (PLAIN epilogue, whole tiles, M % 64 == 0): float2 [M / 64][N] = (mean, M2) of the 64   */
+                                   /*   stored values of every channel per 64-row slab; consumed by iir_groupnorm_from_partials       */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -88,6 +92,8 @@ int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired);
 /* The tile / kernel iir_gemm_f16(d) resolves to, without launching (91: the 8-wave 256x320 kernel of csrc/gemm8.hip, used for the
  * GEGLU projections of module/min_sdxl.py:502-528 when its tiles fill the chip); -1 for an invalid descriptor. */
 int iir_gemm_resolve_tile(const iir_gemm_desc* d);
+/* 1 when the tile = 0, plain-epilogue fp16 launch of (M, N, K) can leave GroupNorm partials in `gn_stats_out` */
+int iir_gemm_gn_supported(int32_t M, int32_t N, int32_t K, int32_t is_conv);
 /* bytes of split-K workspace an (M, N) problem can use (0: the split form does not apply to it) */
 int64_t iir_gemm_splitk_workspace_bytes(int32_t M, int32_t N);
 /* 1 if a tile = 0 launch of this problem with a workspace of ws_bytes takes the two-slice split-K form (128x160 tile) */
@@ -118,6 +124,7 @@ typedef struct iir_conv_desc {
     void* splitk_ws;               /* as in iir_gemm_desc (M = R*Ho*Wo, N = Cout)                  */
     int64_t splitk_ws_bytes;
     int32_t dtype;                 /* IIR_DT_F16 / IIR_DT_BF16, as in iir_gemm_desc                */
+    void* gn_stats_out;            /* as in iir_gemm_desc: float2 [R * Ho * Wo / 64][Cout] (rows of one image must fill whole 64-row slabs) */
 } iir_conv_desc;
 
 /* Replaces nn.Conv2d call sites: ResnetBlock2D module/min_sdxl.py:256-259,274 (+ the temb add :267 as
@@ -151,6 +158,12 @@ int iir_attention_d64_f16(const iir_attn_desc* a, void* stream);
 int iir_groupnorm_nhwc_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,
                            int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
                            void* workspace, int64_t workspace_bytes, void* stream);
+/* nn.GroupNorm (+ SiLU) whose statistics pass already happened in the producing launch (`gn_stats_out` of iir_gemm_f16 /
+ * iir_conv2d_nhwc_f16: float2 [R * HW / 64][ldp] (mean, M2) per 64-row slab and channel): merges the slabs and channels of
+ * every (image, group), then normalises X into Y.  HW % 64 == 0.  Same call sites as iir_groupnorm_nhwc_f16. */
+int iir_groupnorm_from_partials(const void* partials, int64_t ldp, const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R,
+                                int32_t HW, int32_t C, int32_t groups, const void* gamma, const void* beta, float eps, int32_t silu,
+                                void* workspace, int64_t workspace_bytes, int32_t dtype, void* stream);
 /* the same for fp16 or bf16 tensors (X, Y, gamma, beta of type `dtype`): the VAE's GroupNorms (eps 1e-6,
  * module/diffusers_vae/vae.py via unet_2d_ZeroSFT_blocks.py:2804-2874) run on bf16 activations */
 int iir_groupnorm_nhwc(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R, int32_t HW, int32_t C,

@@ -103,6 +103,9 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     float2* rowstat = (float2*)(smem + RING_BYTES + SCRATCH_BYTES);          // [BM] (rstd, -rstd * mean) of this tile's rows (ln_in)
     constexpr int LNP_OFF = (BM * (2 * BN + 32) + 15) / 16 * 16;              // producer partials sit behind the finished output tile
     constexpr bool LN_OUT_FITS = LNP_OFF + BM * (BN / 8) * 8 <= RING_BYTES;
+    // GroupNorm partials (round 3): per-thread column statistics of a 64-row slab meet in [row groups][BN] float2 behind the tile
+    constexpr int GN_RG = NT / (BN / 8);                                     // row groups of the column-fixed write-out mapping
+    constexpr bool GN_OUT_FITS = BM % 64 == 0 && LNP_OFF + GN_RG * BN * 8 <= RING_BYTES && BN <= NT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -625,6 +628,75 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         }
         // (hipcc drains every LDS-DMA in flight at the next use of an ordinary load's result, so the touches are issued
         //  after the residuals have been consumed and ahead of the stores, which need no wait)
+        if constexpr (GN_OUT_FITS && CPR == BN / 8) {
+        if (fast && g.gn_out && !paired) {
+            // Write-out with GroupNorm statistics: thread = (row group rg, 16-byte column chunk cc), so
+            // all rows a thread stores share its 8 channels and their sums stay in registers (taken about the thread's first
+            // sample: no E[x^2] - mean^2 cancellation); per 64-row slab the RG row groups of a column are merged through LDS in
+            // a fixed order by one thread per column -> (mean, M2) of the 64 stored (rounded) values of that channel.  The
+            // finalize kernel merges slabs x channels of an (image, group).  No atomics: bit-reproducible.
+            constexpr int RG = NT / CPR, RPT = (64 + RG - 1) / RG;            // rows per thread and slab
+            const int cc = tid % CPR, rg = tid / CPR;
+            const bool active = rg < RG;
+            float2* part = (float2*)(smem + LNP_OFF);                         // [RG][BN]
+            touch_next_weights();
+#pragma unroll 1
+            for (int half = 0; half < BM / 64; ++half) {
+                E8 rr[RPT];
+                if (use_res) {
+#pragma unroll
+                    for (int j = 0; j < RPT; ++j) {
+                        const int r = half * 64 + min(rg + j * RG, 63);
+                        rr[j] = *(const E8*)(g.res + (long)(m0 + r) * g.ldr + no_tile + min(cc, CPR - 1) * 8);
+                    }
+                }
+                float k0[8], s8[8], q8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { k0[t] = 0.f; s8[t] = 0.f; q8[t] = 0.f; }
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    const int rl = rg + j * RG;
+                    if (active && rl < 64) {
+                        const int r = half * 64 + rl;
+                        const E8 v = *(const E8*)(ct + r * cs + cc * 16);
+                        E8 o;
+                        for (int t = 0; t < 8; ++t) o[t] = (E)(((float)v[t] + (use_res ? (float)rr[j][t] : 0.f)) * g.out_scale);
+                        iir::store16(g.C, ((long)(m0 + r) * g.ldc + no_tile + cc * 8) * 2, o, g.st_wt != 0);
+                        for (int t = 0; t < 8; ++t) {
+                            const float f = (float)o[t];
+                            if (j == 0) k0[t] = f;
+                            const float d = f - k0[t];
+                            s8[t] += d; q8[t] = fmaf(d, d, q8[t]);
+                        }
+                        ++cnt;
+                    }
+                }
+                if (active) {
+                    const float inv = 1.0f / (float)cnt;                      // (cnt >= 1: rg < RG <= 64)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        part[rg * BN + cc * 8 + t] = make_float2(k0[t] + s8[t] * inv, fmaxf(q8[t] - s8[t] * s8[t] * inv, 0.f));
+                }
+                __syncthreads();
+                if (tid < BN) {                                               // one thread per tile column: merge the row groups in order
+                    float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll 4
+                    for (int q = 0; q < RG; ++q) {
+                        const float2 pq = part[q * BN + tid];
+                        const float nb = (float)((64 - q + RG - 1) / RG);     // rows row group q holds in a slab
+                        const float tot = n + nb, d = pq.x - mean;
+                        mean += d * (nb / tot);
+                        m2 += pq.y + d * d * (n * nb / tot);
+                        n = tot;
+                    }
+                    ((float2*)g.gn_out)[(long)(m0 / 64 + half) * g.N + n0 + tid] = make_float2(mean, m2);
+                }
+                __syncthreads();
+            }
+            return;
+        }
+        }
         if (fast) {
             E8 o[CH];
             if (use_res) {
@@ -725,6 +797,13 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     g.tiles_n = (g.N + BN - 1) / BN;
     static const size_t dbg_pad = getenv("IIR_DBG_LDS_PAD") ? (size_t)atoi(getenv("IIR_DBG_LDS_PAD")) : 0;     // (5.8 bisection: force one workgroup per CU)
     const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 256 * WAVES_M * 2 * (LW ? 2 : 1) + BM * 8 + dbg_pad;   // ring (reused as the output tile) + prefetch scratch (256 B per wave) + LayerNorm row statistics
+    if (g.gn_out) {         // producer of GroupNorm partials: whole tiles, 16-byte rows, plain epilogue, rows of an image tile-aligned (caller)
+        constexpr int RINGB = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)), NTH = 128 * WAVES_M * (LW ? 2 : 1);
+        constexpr bool fits = BM % 64 == 0 && BN <= NTH && (BM * (2 * BN + 32) + 15) / 16 * 16 + (NTH / (BN / 8)) * BN * 8 <= RINGB;
+        if (!fits || g.epi != IIR_EPI_PLAIN || g.c_f32 || g.Ct || g.splitk == 2 || g.ln_out || g.M % BM || g.N % BN || !g.c_vec || (g.res && !g.r_vec) ||
+            (conv && (g.y_img_rows | g.res_img_rows)))
+            return IIR_EINVAL;
+    }
     if (g.ln_out) {         // producer of LayerNorm partials: whole tiles, 16-byte rows, plain epilogue (see the kernel's fast write-out path)
         constexpr bool fits = (BM * (2 * BN + 32) + 15) / 16 * 16 + BM * (BN / 8) * 8 <= ST * (BM * 128 + (W8 ? BN * 64 : BN * 128));
         if (!fits || conv || g.epi != IIR_EPI_PLAIN || g.c_f32 || g.Ct || g.splitk == 2 || g.M % BM || g.N % BN || !g.c_vec || (g.res && !g.r_vec))
@@ -863,7 +942,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // of K on exactly those (51.8 vs 44.8 us warm at K = 5120, equal at K = 11520, 73.9 vs 73.0 ms per step): the agent-scope
     // release per workgroup and the fp32 slab round trip cost more than the smaller operand fill saves.  The engine does
     // not pass a workspace unless IIR_SPLITK=1.
-    if (tile == 0 && g.sk_slabs && !g.ln_out && !g.ln_in && g.dtype == IIR_DT_F16 && uses_splitk(g.M, g.N, g.K, g.sk_bytes)) {
+    if (tile == 0 && g.sk_slabs && !g.ln_out && !g.ln_in && !g.gn_out && g.dtype == IIR_DT_F16 && uses_splitk(g.M, g.N, g.K, g.sk_bytes)) {
         Geo g2 = g;
         g2.splitk = 2;
         return launch<128, 160, 3>(g2, conv, stream);
@@ -955,6 +1034,22 @@ extern "C" int iir_gemm_ln_parts(int32_t M, int32_t N, int32_t K) {
 
 static int fill_gemm_geo(const iir_gemm_desc* d, Geo& g);
 
+// 1 when the tile = 0 launch of an (M, N, K) GEMM / implicit-GEMM conv (plain epilogue, fp16) can leave GroupNorm partials
+// (`gn_stats_out`): whole tiles and room for the column partials behind the staged output tile.
+extern "C" int iir_gemm_gn_supported(int32_t M, int32_t N, int32_t K, int32_t is_conv) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % 64) return 0;
+    const int t = pick_tile(M, N, false, K);
+    if (t < 1 || t > 5) return 0;
+    const int bm = kTiles[t].bm, bn = kTiles[t].bn;
+    if (M % bm || N % bn) return 0;
+    const long blocks = (long)(M / bm) * (N / bn);
+    const bool lw = t == 5 && blocks <= 256 && K >= one_per_cu_min_k() && one_per_cu_stages() == 3;
+    const int st = lw ? 3 : IIR_DEFAULT_STAGES, nt = lw ? 512 : 256;
+    const long ring = (long)st * (bm + bn) * 128, need = ((long)bm * (2 * bn + 32) + 15) / 16 * 16 + (long)(nt / (bn / 8)) * bn * 8;
+    (void)is_conv;
+    return bn <= nt && need <= ring ? 1 : 0;
+}
+
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     (void)hipGetLastError();
     Geo g{};
@@ -1010,6 +1105,10 @@ static int fill_gemm_geo(const iir_gemm_desc* d, Geo& g) {
         if ((uintptr_t)d->ln_stats_out % 8 || d->c_f32 || d->Ct || d->epi != IIR_EPI_PLAIN) return IIR_EINVAL;
         g.ln_out = (float*)d->ln_stats_out;
     }
+    if (d->gn_stats_out) {
+        if ((uintptr_t)d->gn_stats_out % 8 || d->M % 64 || d->epi != IIR_EPI_PLAIN || d->c_f32 || d->Ct || d->ln_stats_out || d->wscale) return IIR_EINVAL;
+        g.gn_out = (float*)d->gn_stats_out;
+    }
     if (d->ln_stats_in) {
         if (!d->ln_colsum || d->ln_parts <= 0 || d->ln_parts > 8 || d->ln_part_cols <= 0 || (long)d->ln_parts * d->ln_part_cols != d->K || d->c_f32 ||
             (uintptr_t)d->ln_stats_in % 8 || (uintptr_t)d->ln_colsum % 16 || !(d->ln_eps > 0.f)) return IIR_EINVAL;
@@ -1048,6 +1147,10 @@ extern "C" int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream) {
     g.dtype = c->dtype;
     g.x_img_stride = c->x_img_stride ? c->x_img_stride : (int64_t)c->H * c->Wd * c->ldx;
     g.y_img_rows = c->y_img_rows; g.res_img_rows = c->res_img_rows;
+    if (c->gn_stats_out) {
+        if ((uintptr_t)c->gn_stats_out % 8 || (g.Ho * g.Wo) % 64 || c->epi != IIR_EPI_PLAIN || c->y_img_rows || c->res_img_rows) return IIR_EINVAL;
+        g.gn_out = (float*)c->gn_stats_out;
+    }
     if (c->splitk_ws && c->splitk_ws_bytes > SK_CNT_BYTES) {
         g.sk_cnt = (int*)c->splitk_ws; g.sk_slabs = (float*)((char*)c->splitk_ws + SK_CNT_BYTES); g.sk_bytes = c->splitk_ws_bytes;
     }

@@ -52,6 +52,7 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     const float* ln_in;             // consumer: those partials; A holds the RAW rows, W has gamma folded in
     int ln_parts, ln_part_cols;     //   partial count per row and the columns each one covers
     float ln_eps;
+    float* gn_out;                  // GroupNorm statistics of the rows this launch writes: [M / 64][N] (mean, M2) per 64-row slab and channel
     int st_wt;                      // write the output through to memory (sc1 stores): nothing is left dirty in the L2s for the end-of-kernel write-back
     const float* ln_colsum;         //   s[n] = sum_k W[n][k] (fp32): y = rstd * (x . w_n) - rstd * mean * s[n] (+ bias, which carries W . beta)
 };

@@ -156,6 +156,53 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int
     }
 }
 
+// ---- GroupNorm pass 2': (mean, rstd) per (image, group) from the PRODUCER's column partials (round 3): the launch that wrote
+// the tensor left (mean, M2) of every channel per 64-row slab (`gn_stats_out`); one workgroup per (image, group) merges its
+// slabs x channels -- equal counts, so mean = average of the means and M2 = sum M2 + 64 * sum (mean_i - mean)^2, two block
+// reductions in a fixed tree.  All loads unconditional and clamped (section 5.8 rule), masked at the merge.
+__global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float2* part, long ldp, int slabs_per_img, int G, int cpg, float eps,
+                                                               float* stat /*[R][G][2]*/) {
+    __shared__ float red[256];
+    const int r = blockIdx.x / G, gi = blockIdx.x - r * G;
+    const int n = slabs_per_img * cpg;                                 // partials of this (image, group), 64 samples each
+    constexpr int MAXP = 20;                                           // n <= 5120 (512 slabs x 10 channels: the Aggregator's 256 x 128 level-0 maps)
+    float2 a[MAXP];
+    const float2* base = part + (long)r * slabs_per_img * ldp + gi * cpg;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int i = min((int)threadIdx.x + k * 256, n - 1);
+        const int sl = i / cpg, c = i - sl * cpg;
+        a[k] = base[(long)sl * ldp + c];
+    }
+    auto block_sum = [&](float v) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+#pragma unroll
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        const float t = red[0];
+        __syncthreads();
+        return t;
+    };
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) sm += ((int)threadIdx.x + k * 256 < n) ? a[k].x : 0.f;
+    const float mean = block_sum(sm) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const float d = a[k].x - mean;
+        q += ((int)threadIdx.x + k * 256 < n) ? fmaf(64.0f * d, d, a[k].y) : 0.f;
+    }
+    const float m2 = block_sum(q);
+    if (threadIdx.x == 0) {
+        stat[((long)r * G + gi) * 2] = mean;
+        stat[((long)r * G + gi) * 2 + 1] = rsqrtf(m2 / ((float)n * 64.0f) + eps);
+    }
+}
+
 // ---- GroupNorm pass 3: normalize + affine (+SiLU).  A thread owns fixed 8-channel chunks, so its 16
 // scale/shift coefficients live in registers and the pixel loop is load - 8 fma - store.
 template <typename E>
@@ -436,6 +483,28 @@ extern "C" int iir_groupnorm_nhwc(const void* X, int64_t ldx, void* Y, int64_t l
     else hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(nslab, R), dim3(256), 0, st, (const f16*)X, (long)ldx, HW, C, groups, pps, part);
     const int gblocks = (groups + 7) / 8;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(R * gblocks), dim3(256), 0, st, (const float*)part, nslab, groups, HW, pps, C / groups, eps, stat, gblocks);
+    if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(nblk, R), dim3(256), 0, st, (const f16*)X, (long)ldx, (f16*)Y, (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
+    else hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(nblk, R), dim3(256), 0, st, (const f16*)X, (long)ldx, (f16*)Y, (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
+    return iir_launch_status();
+}
+
+extern "C" int iir_groupnorm_from_partials(const void* partials, int64_t ldp, const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t R,
+                                           int32_t HW, int32_t C, int32_t groups, const void* gamma, const void* beta, float eps,
+                                           int32_t silu, void* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!partials || !X || !Y || !gamma || !beta || !workspace || (uintptr_t)partials % 8) return IIR_EINVAL;
+    if (C % 8 || C > GN_MAXC || groups <= 0 || groups > 64 || C % groups || ldx % 8 || ldy % 8 || ldp < C) return IIR_EINVAL;
+    if (R <= 0 || HW <= 0 || HW % 64 || (dtype != IIR_DT_F16 && dtype != IIR_DT_BF16)) return IIR_EINVAL;
+    const int slabs = HW / 64, cpg = C / groups;
+    if ((long)slabs * cpg > 20 * 256) return IIR_EINVAL;
+    if ((int64_t)R * groups * 2 * 4 > workspace_bytes) return IIR_EINVAL;
+    float* stat = (float*)workspace;
+    const hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(R * groups), dim3(256), 0, st, (const float2*)partials, (long)ldp, slabs, groups, cpg, eps, stat);
+    int nblk = (1024 + R - 1) / R;
+    static const int min_ppb = getenv("IIR_GN_APPLY_MINPIX") ? atoi(getenv("IIR_GN_APPLY_MINPIX")) : 8;
+    int ppb = (HW + nblk - 1) / nblk; if (ppb < min_ppb) ppb = min_ppb;
+    nblk = (HW + ppb - 1) / ppb;
     if (dtype == IIR_DT_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(nblk, R), dim3(256), 0, st, (const f16*)X, (long)ldx, (f16*)Y, (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
     else hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(nblk, R), dim3(256), 0, st, (const f16*)X, (long)ldx, (f16*)Y, (long)ldy, HW, C, groups, ppb, (const float*)stat, (const f16*)gamma, (const f16*)beta, silu);
     return iir_launch_status();

@@ -152,6 +152,9 @@ class _Net:
         # LayerNorm folded into the GEMMs either side of it (ops.LnFold; iir_gemm_desc.ln_stats_out / ln_stats_in): not with fp8
         # operands (the activation would be rounded to 3 mantissa bits BEFORE its row mean is removed)
         self.ln_fold = os.environ.get("IIR_LN_FOLD", "1") != "0" and not fp8_linear
+        # GroupNorm statistics from the launch that produces the GroupNorm's input (ops.gemm / conv2d `gn_out=`, round 3): the
+        # producer tags its output tensor with the partials, the GroupNorm that consumes it skips its statistics pass
+        self.gn_fuse = os.environ.get("IIR_GN_FUSE", "1") != "0"
         self._pack_encoder(sd)
 
     # ---- weight packing ---------------------------------------------------------------------
@@ -353,6 +356,18 @@ class _Net:
     def _begin(self):
         self.arena.reset()
 
+    def _gn_alloc(self, rows, hw, C, K, conv):
+        """Arena room for the GroupNorm partials of a (rows, C) tensor about to be produced by a (rows, C, K) launch -- fp32
+        (rows / 64, C, 2) -- or None when the fused path does not apply (images not made of whole 64-row slabs, tiles that cannot
+        emit them).  Allocation happens in the sizing dry run as well: static addresses."""
+        if not self.gn_fuse or hw % 64 or self.arena.dtype != F16 or not ops.gn_supported(rows, C, K, conv):
+            return None
+        return self.arena.alloc(rows // 64 * C, 4).view(torch.float32).view(rows // 64, C, 2)
+
+    @staticmethod
+    def _gn_of(x):
+        return getattr(x, "_gn_parts", None)
+
     # ---- blocks -----------------------------------------------------------------------------
     def _resnet(self, path, x, R, H, W, temb_all, out=None, eps=1e-5):
         """x (R*H*W, Cin) view -> (R*H*W, Cout).  module/min_sdxl.py:261-283."""
@@ -363,22 +378,27 @@ class _Net:
         cout = w[path + ".conv1.w"].shape[0]
         if out is None:
             out = A.alloc(R * HW, cout)
+        p_out = self._gn_alloc(R * HW, HW, cout, 9 * cout, True) if self._skws is None else None     # partials of this block's output
         m = A.mark()
         h = A.alloc(R * HW, cin)
-        o.groupnorm(x, h, R, HW, w[path + ".norm1.g"], w[path + ".norm1.b"], eps, True, self.cfg.norm_groups, self._gnws)
+        o.groupnorm(x, h, R, HW, w[path + ".norm1.g"], w[path + ".norm1.b"], eps, True, self.cfg.norm_groups, self._gnws,
+                    partials=self._gn_of(x))
         h2 = A.alloc(R * HW, cout)
+        p2 = self._gn_alloc(R * HW, HW, cout, 9 * cin, True) if self._skws is None else None
         o.conv2d(h.view(R, H, W, cin), w[path + ".conv1.w"], h2, bias=w[path + ".conv1.b"],
                  rowbias=temb_all[:, self._temb_slices[path]], rows_per_rb=HW, prefetch=self._pf(w[path + ".conv1.w"]),
-                 splitk_ws=self._skws)
+                 splitk_ws=self._skws, gn_out=p2)
         h3 = A.alloc(R * HW, cout)
-        o.groupnorm(h2, h3, R, HW, w[path + ".norm2.g"], w[path + ".norm2.b"], eps, True, self.cfg.norm_groups, self._gnws)
+        o.groupnorm(h2, h3, R, HW, w[path + ".norm2.g"], w[path + ".norm2.b"], eps, True, self.cfg.norm_groups, self._gnws, partials=p2)
         if (path + ".conv_shortcut.w") in w:
             sc = A.alloc(R * HW, cout)
             o.gemm(x, w[path + ".conv_shortcut.w"], sc, bias=w[path + ".conv_shortcut.b"])
         else:
             sc = x
         o.conv2d(h3.view(R, H, W, cout), w[path + ".conv2.w"], out, bias=w[path + ".conv2.b"], res=sc,
-                 prefetch=self._pf(w[path + ".conv2.w"]), splitk_ws=self._skws)
+                 prefetch=self._pf(w[path + ".conv2.w"]), splitk_ws=self._skws, gn_out=p_out)
+        if p_out is not None:
+            out._gn_parts = p_out
         A.release(m)
         return out
 
@@ -449,9 +469,11 @@ class _Net:
         T = H * W
         if out is None:
             out = A.alloc(R * T, C)
+        p_out = self._gn_alloc(R * T, T, C, C, False)            # partials of the block's output (proj_out + residual)
         m = A.mark()
         g = A.alloc(R * T, C)
-        o.groupnorm(x, g, R, T, w[path + ".norm.g"], w[path + ".norm.b"], 1e-6, False, self.cfg.norm_groups, self._gnws)
+        o.groupnorm(x, g, R, T, w[path + ".norm.g"], w[path + ".norm.b"], 1e-6, False, self.cfg.norm_groups, self._gnws,
+                    partials=self._gn_of(x))
         h = A.alloc(R * T, C)
         # LayerNorm folding needs every GEMM that writes h (K = C: proj_in, to_out; K = 4C: ff2) to leave the same partials layout
         lnst = None
@@ -462,7 +484,10 @@ class _Net:
         o.gemm(g, w[path + ".proj_in.w"], h, bias=w[path + ".proj_in.b"], ln_out=lnst)
         for k in range(depth):
             self._tblock(f"{path}.transformer_blocks.{k}", h, R, T, C // self.cfg.head_dim, st, ada, lnst, last=k == depth - 1)
-        o.gemm(h, w[path + ".proj_out.w"], out, bias=w[path + ".proj_out.b"], res=x)
+        o.gemm(h, w[path + ".proj_out.w"], out, bias=w[path + ".proj_out.b"], res=x,
+               gn_out=p_out if not isinstance(w[path + ".proj_out.w"], ops.Fp8Weight) else None)
+        if p_out is not None and not isinstance(w[path + ".proj_out.w"], ops.Fp8Weight):
+            out._gn_parts = p_out
         A.release(m)
         return out
 
@@ -520,7 +545,10 @@ class _Net:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 H2, W2 = (H + 1) // 2, (W + 1) // 2
                 y = A.alloc(R * H2 * W2, c)
-                o.conv2d(x.view(R, H, W, c), w[p + ".w"], y, stride=2, bias=w[p + ".b"])
+                py = self._gn_alloc(R * H2 * W2, H2 * W2, c, 9 * c, True)
+                o.conv2d(x.view(R, H, W, c), w[p + ".w"], y, stride=2, bias=w[p + ".b"], gn_out=py)
+                if py is not None:
+                    y._gn_parts = py
                 x, H, W = y, H2, W2
                 skips.append((x, H, W))
         x = self._resnet("mid_block.resnets.0", x, R, H, W, temb_all)
@@ -694,7 +722,10 @@ class HipUNet(_Net):
         R, H, W = st["R"], st["H"], st["W"]
         temb_all, ada = self._embeddings(t_dev, st)
         x = A.alloc(R * H * W, cfg.block_out_channels[0])
-        o.conv2d(sample.view(R, H, W, CPAD), w["conv_in.w"], x, bias=w["conv_in.b"])
+        px = self._gn_alloc(R * H * W, H * W, cfg.block_out_channels[0], 9 * CPAD, True)
+        o.conv2d(sample.view(R, H, W, CPAD), w["conv_in.w"], x, bias=w["conv_in.b"], gn_out=px)
+        if px is not None:
+            x._gn_parts = px
         x, h, wd, skips = self._down_and_mid(x, R, H, W, temb_all, ada, st)
         return x, h, wd, skips, temb_all, ada
 
@@ -734,7 +765,8 @@ class HipUNet(_Net):
                 x, h, wd = y, 2 * h, 2 * wd
         c0 = cfg.block_out_channels[0]
         g = A.alloc(R * h * wd, c0)
-        o.groupnorm(x, g, R, h * wd, w["conv_norm_out.g"], w["conv_norm_out.b"], 1e-5, True, cfg.norm_groups, self._gnws)
+        o.groupnorm(x, g, R, h * wd, w["conv_norm_out.g"], w["conv_norm_out.b"], 1e-5, True, cfg.norm_groups, self._gnws,
+                    partials=self._gn_of(x))
         eps = A.alloc(R * h * wd, cfg.out_channels)
         o.conv2d(g.view(R, h, wd, c0), w["conv_out.w"], eps, bias=w["conv_out.b"])
         return eps

@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("wscale", C.c_void_p),
         ("ln_stats_out", C.c_void_p), ("ln_stats_in", C.c_void_p), ("ln_parts", C.c_int32), ("ln_part_cols", C.c_int32),
         ("ln_eps", C.c_float), ("ln_colsum", C.c_void_p),
+        ("gn_stats_out", C.c_void_p),
     ]
 
 
@@ -58,6 +59,7 @@ class ConvDesc(C.Structure):
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("dtype", C.c_int32),
+        ("gn_stats_out", C.c_void_p),
     ]
 
 
@@ -97,12 +99,14 @@ SIGNATURES = {
     "iir_gemm_uses_splitk": (C.c_int, [_I32, _I32, _I32, _I64]),
     "iir_gemm_pick_tile": (C.c_int, [_I32, _I32, _I32, _I32]),
     "iir_gemm_resolve_tile": (C.c_int, [_P]),
+    "iir_gemm_gn_supported": (C.c_int, [_I32, _I32, _I32, _I32]),
     "iir_gemm_tile_bn": (C.c_int, [_I32]),
     "iir_gemm_ln_parts": (C.c_int, [_I32, _I32, _I32]),
     "iir_conv2d_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "iir_attention_d64_f16": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "iir_groupnorm_nhwc_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _P]),
     "iir_groupnorm_nhwc": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _I32, _P]),
+    "iir_groupnorm_from_partials": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _F, _I32, _P, _I64, _I32, _P]),
     "iir_groupnorm_workspace_bytes": (C.c_int64, [_I32, _I32]),
     "iir_layernorm_f16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _F, _P, _P, _I64, _I32, _I32, _I32, _I64, _P]),
     "iir_adaln_batch_f16": (C.c_int, [_P, _I32, _I32, _I32, _F, _I64, _I32, _I32, _I64, _P]),

@@ -160,8 +160,19 @@ def ln_parts(M, N, K):
     return L.load().iir_gemm_ln_parts(M, N, K)
 
 
+def gn_supported(M, N, K, conv=False):
+    """Can the tile = 0 launch of (M, N, K) leave GroupNorm partials (`gn_out=`)?"""
+    return bool(L.load().iir_gemm_gn_supported(M, N, K, int(conv)))
+
+
+def _chk_gn_out(gn_out, M, N):
+    """GroupNorm partials of a producing launch: fp32 (M / 64, N, 2), contiguous (`iir_gemm_desc.gn_stats_out`)."""
+    if gn_out.dtype != torch.float32 or not gn_out.is_contiguous() or M % 64 or tuple(gn_out.shape) != (M // 64, N, 2):
+        raise ValueError(f"gn_out: contiguous fp32 ({M} // 64, {N}, 2) with M % 64 == 0, got {tuple(gn_out.shape)} {gn_out.dtype}")
+
+
 def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
-         tile=0, prefetch=None, splitk_ws=None, out_t=None, wscale=None, ln_out=None, ln_in=None):
+         tile=0, prefetch=None, splitk_ws=None, out_t=None, wscale=None, ln_out=None, ln_in=None, gn_out=None):
     """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues).
     out_t = (Ct, tr_from): output columns >= tr_from go, transposed, to Ct[n - tr_from, m]; `out` then is (M, tr_from).
     wscale (fp32 (N,)): `w` holds fp8-E4M3 bytes (torch.float8_e4m3fn / uint8) with that per-row scale (fp8 MFMA).
@@ -214,6 +225,9 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
                 or ln_out.shape[0] != ln_parts(M, N, K) or tile != 0:
             raise ValueError("ln_out: contiguous fp32 (ln_parts(M, N, K), M, 2), tile = 0")
         d.ln_stats_out = ln_out.data_ptr()
+    if gn_out is not None:
+        _chk_gn_out(gn_out, M, N)
+        d.gn_stats_out = gn_out.data_ptr()
     if ln_in is not None:
         part, colsum, eps = ln_in
         if part.dtype != torch.float32 or not part.is_contiguous() or part.dim() != 3 or part.shape[1:] != (M, 2) or K % part.shape[0]:
@@ -246,7 +260,7 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
 
 def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None, rows_per_rb=1, res=None,
            epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0, tile=0, y_img_rows=0, res_img_rows=0, pad_mode=0, prefetch=None,
-           splitk_ws=None):
+           splitk_ws=None, gn_out=None):
     """x (R,H,W,Cin) NHWC view (pixel stride x.stride(2), image stride x.stride(0) free), w (Cout,k,k,Cin) contiguous,
     out (rows, Cout[/2]) 2-D view; image i's pixels start at row i*y_img_rows (0 = dense)."""
     R, H, Wd, Cin = x.shape
@@ -278,6 +292,9 @@ def conv2d(x, w, out, ksize=3, stride=1, upsample=False, bias=None, rowbias=None
     pad2 = 1 if pad_mode == 1 else 2 * (ksize // 2)
     Mo = R * ((Hi + pad2 - ksize) // stride + 1) * ((Wi + pad2 - ksize) // stride + 1)
     d.epi, d.act, d.out_scale, d.tile = epi, act, out_scale, tile
+    if gn_out is not None:
+        _chk_gn_out(gn_out, Mo, Cout)
+        d.gn_stats_out = gn_out.data_ptr()
     if tile == 0:       # as in gemm(): the library decides, this only names the launch
         Kc = ksize * ksize * Cin
         tile = 4 if splitk_ws is not None and L.load().iir_gemm_uses_splitk(Mo, Cout, Kc, splitk_ws.numel()) else auto_tile(Mo, Cout, epi != EPI_PLAIN, Kc)
@@ -343,8 +360,10 @@ def gn_workspace(device, R, groups=32):
     return torch.empty(L.load().iir_groupnorm_workspace_bytes(R, groups) // 4, dtype=torch.float32, device=device)
 
 
-def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32, ws=None):
-    """x, out: 2-D views (R*HW, C).  `ws`: scratch from gn_workspace() (a shared per-stream one if omitted)."""
+def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32, ws=None, partials=None):
+    """x, out: 2-D views (R*HW, C).  `ws`: scratch from gn_workspace() (a shared per-stream one if omitted).
+    `partials` (fp32 (R*HW / 64, C, 2)): the statistics the launch that PRODUCED x left (`gn_out=` of gemm / conv2d): no
+    statistics pass over x."""
     dt = x.dtype
     _chk2d(x, "x", dt if dt in _DT else torch.float16); _chk2d(out, "out", dt)
     if gamma.dtype != dt or beta.dtype != dt:
@@ -352,6 +371,12 @@ def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32, ws=None):
     Cc = x.shape[1]
     if ws is None:
         ws = _gn_workspace(x.device, R, groups)
+    if partials is not None:
+        _chk_gn_out(partials, R * HW, Cc)
+        L.check(L.load().iir_groupnorm_from_partials(partials.data_ptr(), Cc, x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
+                                                     R, HW, Cc, groups, gamma.data_ptr(), beta.data_ptr(), eps, int(silu), ws.data_ptr(),
+                                                     ws.numel() * 4, _DT[dt], _stream()), "iir_groupnorm_from_partials")
+        return out
     L.check(L.load().iir_groupnorm_nhwc(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, HW, Cc, groups,
                                         gamma.data_ptr(), beta.data_ptr(), eps, int(silu), ws.data_ptr(),
                                         ws.numel() * 4, _DT[dt], _stream()), "iir_groupnorm_nhwc")

@@ -647,3 +647,74 @@ def test_cross_attention_prestaged(dev, T):
     ops.attention(q.reshape(-1, C).to(dev), o, segs, B, heads, T)
     torch.cuda.synchronize()
     _close(o, want.reshape(B * T, C), rtol=3e-3, atol=3e-3, what="text + IP cross-attention")
+
+
+# ---- round 3: GroupNorm statistics from the producing launch ---------------------------------------------------------------
+def _slab_stats(y):
+    """(mean, M2) per 64-row slab and channel of a (rows, C) tensor, fp64."""
+    z = y.double().reshape(-1, 64, y.shape[1])
+    mu = z.mean(1)
+    return mu, ((z - mu[:, None]) ** 2).sum(1)
+
+
+@pytest.mark.parametrize("M,N,K,res", [(2048, 1280, 1280, True), (8192, 640, 640, True), (2048, 320, 640, False), (256, 640, 128, True)])
+def test_gemm_groupnorm_partials(dev, M, N, K, res):
+    """`gn_out`: the GEMM that writes a GroupNorm's input leaves (mean, M2) of the STORED fp16 values per 64-row slab and channel
+    (module/min_sdxl.py:565-595: proj_out + residual -> next block's GroupNorm)."""
+    from instantir_amd import ops
+    if not ops.gn_supported(M, N, K):
+        pytest.skip("tile of this shape cannot emit partials")
+    g = torch.Generator().manual_seed(M + N)
+    a, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
+    r = (_rand(g, M, N).float() + 3.0 * torch.randn(1, N, generator=g)).half() if res else None      # channel means far above the spread
+    out = torch.empty(M, N, dtype=torch.half, device=dev)
+    part = torch.zeros(M // 64, N, 2, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out, bias=b.to(dev), res=r.to(dev) if res else None, gn_out=part)
+    plain = torch.empty_like(out)
+    ops.gemm(a.to(dev), w.to(dev), plain, bias=b.to(dev), res=r.to(dev) if res else None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain), "the statistics path changed the stored output"
+    mu, m2 = _slab_stats(out.cpu())
+    np.testing.assert_allclose(part[:, :, 0].cpu().numpy(), mu.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(part[:, :, 1].cpu().numpy(), m2.numpy(), rtol=3e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("R,H,Cin,Cout,stride,with_res", [(2, 32, 1280, 1280, 1, True), (2, 64, 640, 640, 1, False), (1, 64, 320, 320, 1, True),
+                                                          (2, 64, 640, 640, 2, False), (2, 16, 64, 320, 1, False)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_conv_groupnorm_from_partials(dev, R, H, Cin, Cout, stride, with_res, silu):
+    """conv (+ temb row bias, + residual) -> GroupNorm (+ SiLU) without a statistics pass: the conv's `gn_out` partials feed
+    `groupnorm(partials=...)`; against torch's group_norm on the conv's stored output, and against the three-launch form."""
+    from instantir_amd import ops
+    from instantir_amd.packing import conv_weight_nhwc
+    Ho = H // stride
+    Mo, HW = R * Ho * Ho, Ho * Ho
+    if HW % 64 or not ops.gn_supported(Mo, Cout, 9 * Cin, True):
+        pytest.skip("geometry without whole 64-row slabs / tile cannot emit partials")
+    g = torch.Generator().manual_seed(H + Cin + stride)
+    x = _rand(g, R, H, H, Cin)
+    w = _rand(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
+    b, rb = _rand(g, Cout), _rand(g, R, Cout)
+    res = (_rand(g, Mo, Cout).float() + 2.0).half() if with_res else None
+    gam, bet = (1.0 + 0.2 * torch.randn(Cout, generator=g)).half(), (0.2 * torch.randn(Cout, generator=g)).half()
+    y = torch.empty(Mo, Cout, dtype=torch.half, device=dev)
+    part = torch.zeros(Mo // 64, Cout, 2, dtype=torch.float32, device=dev)
+    kw = dict(stride=stride, bias=b.to(dev), rowbias=rb.to(dev), rows_per_rb=HW, res=res.to(dev) if with_res else None)
+    ops.conv2d(x.to(dev), conv_weight_nhwc(w).to(dev), y, gn_out=part, **kw)
+    y0 = torch.empty_like(y)
+    ops.conv2d(x.to(dev), conv_weight_nhwc(w).to(dev), y0, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    mu, m2 = _slab_stats(y.cpu())
+    np.testing.assert_allclose(part[:, :, 0].cpu().numpy(), mu.numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(part[:, :, 1].cpu().numpy(), m2.numpy(), rtol=3e-4, atol=2e-3)
+    ws = ops.gn_workspace(dev, R, 32)
+    fused, three = torch.empty_like(y), torch.empty_like(y)
+    ops.groupnorm(y, fused, R, HW, gam.to(dev), bet.to(dev), 1e-5, silu, 32, ws, partials=part)
+    ops.groupnorm(y, three, R, HW, gam.to(dev), bet.to(dev), 1e-5, silu, 32, ws)
+    torch.cuda.synchronize()
+    yn = y.float().cpu().reshape(R, HW, Cout).permute(0, 2, 1)
+    want = F.group_norm(yn, 32, gam.float(), bet.float(), 1e-5)
+    want = (F.silu(want) if silu else want).permute(0, 2, 1).reshape(Mo, Cout)
+    _close(fused, want, rtol=4e-3, atol=4e-3, what="GroupNorm from producer partials")
+    assert (fused.float() - three.float()).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())
