@@ -362,6 +362,8 @@ class _Net:
         emit them).  Allocation happens in the sizing dry run as well: static addresses."""
         if not self.gn_fuse or hw % 64 or self.arena.dtype != F16 or not ops.gn_supported(rows, C, K, conv):
             return None
+        if (hw // 64) * (C // 32) > ops.GN_PARTIALS_MAX:          # iir_groupnorm_from_partials merges at most this many per (image, group)
+            return None
         return self.arena.alloc(rows // 64 * C, 4).view(torch.float32).view(rows // 64, C, 2)
 
     @staticmethod

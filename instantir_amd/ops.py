@@ -160,6 +160,9 @@ def ln_parts(M, N, K):
     return L.load().iir_gemm_ln_parts(M, N, K)
 
 
+GN_PARTIALS_MAX = 20 * 256          # slabs x channels-per-group one (image, group) of iir_groupnorm_from_partials may hold (csrc/norm.hip)
+
+
 def gn_supported(M, N, K, conv=False):
     """Can the tile = 0 launch of (M, N, K) leave GroupNorm partials (`gn_out=`)?"""
     return bool(L.load().iir_gemm_gn_supported(M, N, K, int(conv)))
@@ -373,6 +376,9 @@ def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32, ws=None, partial
         ws = _gn_workspace(x.device, R, groups)
     if partials is not None:
         _chk_gn_out(partials, R * HW, Cc)
+        if HW % 64 or (HW // 64) * (Cc // groups) > GN_PARTIALS_MAX:
+            raise ValueError(f"groupnorm(partials=): images of whole 64-row slabs and at most {GN_PARTIALS_MAX} partials per (image, group); "
+                             f"got HW={HW}, {Cc // groups} channels per group")
         L.check(L.load().iir_groupnorm_from_partials(partials.data_ptr(), Cc, x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
                                                      R, HW, Cc, groups, gamma.data_ptr(), beta.data_ptr(), eps, int(silu), ws.data_ptr(),
                                                      ws.numel() * 4, _DT[dt], _stream()), "iir_groupnorm_from_partials")
