@@ -205,6 +205,116 @@ __global__ __launch_bounds__(NW * 64) void fill_kernel(const f16* __restrict__ A
     if (acc == 123.456f) sink[0] = acc;
 }
 
+
+// ---- "B direct" probe: the weight operand never touches LDS.  4 waves laid out 1 (M) x 4 (N) over the 64 x 160 tile: wave w owns
+// the 16-column blocks {w, w+4, w+8 (waves 0,1 only)}; its weight fragments come straight from memory into registers (16 rows x
+// 64 B per instruction, the MFMA B-operand layout), three K tiles deep; the activation tile (64 rows x 128 B) goes through the
+// LDS-DMA ring as before and every wave reads all of it.  Per K tile and CU: 8 KiB DMA + 20 KiB register loads through the
+// vector memory path, 32 KiB of fragment reads, 24 / 16 MFMA 16x16x32 per wave.  FULL = 0: no MFMA (loads + reads only).
+template <int FULL>
+__global__ __launch_bounds__(256, 2) void bd_kernel(const f16* __restrict__ A, const f16* __restrict__ W, int K, int reps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int tm = x * 4 + (l & 3), tn = l >> 2;
+    const int nk = K / 64, total = nk * reps;
+    constexpr int ST = 3;
+    const int nblk = wave < 2 ? 3 : 2;
+    // A staging: 8 pieces of 8 rows, 2 per wave
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const f16* asrc[2];
+    for (int i = 0; i < 2; ++i) asrc[i] = A + (long)(tm * 64 + (i * 4 + wave) * 8 + srow) * K + schunk * 8;
+    auto stage_a = [&](int t, int buf) {
+        const int k0 = (t % nk) * 64;
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(asrc[i] + k0), (LDS_AS void*)(smem + buf * 8192 + (i * 4 + wave) * 1024), 16, 0, 0);
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    const f16* bsrc[3];
+    // FULL & 2: fragment-major weights (packed once at load time): [N / 16][K / 32][64 lanes][8 halves], a whole B fragment is one
+    // contiguous KiB in lane order (fully coalesced); otherwise row-major [N][K]: 16 rows x 64 B per instruction
+    for (int j = 0; j < 3; ++j)
+        bsrc[j] = (FULL & 2) ? W + (long)(tn * 10 + min(wave + 4 * j, 9)) * (K / 32) * 512 + lane * 8
+                             : W + (long)(tn * 160 + min(wave + 4 * j, 9) * 16 + frow) * K + fq * 8;
+    h8 b[3][3][2];
+    // register loads in asm (the compiler's own bookkeeping turns every wait in this loop into vmcnt(0)); all waves issue three
+    // blocks (waves 2, 3: the third is a clamped duplicate) so the counts are uniform
+    auto load_b = [&](int t, h8 (&r)[3][2]) {
+        const int k0 = (FULL & 2) ? (t % nk) * 1024 : (t % nk) * 64, k1 = (FULL & 2) ? k0 + 512 : k0 + 32;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[j][0]) : "v"(bsrc[j] + k0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[j][1]) : "v"(bsrc[j] + k1) : "memory");
+        }
+    };
+    f4 acc[4][3];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) acc[i][j] = (f4){0, 0, 0, 0};
+    h8 asum = {0, 0, 0, 0, 0, 0, 0, 0};
+    stage_a(0, 0); load_b(0, b[0]); stage_a(1, 1); load_b(1, b[1]); load_b(2, b[2]);
+    auto body = [&](int t, int buf, h8 (&r)[3][2]) {
+        // issue order per iteration: A(i+2) [2 DMA], B(i+3) [6 loads]; before iteration t the queue holds, oldest first,
+        // B(t), A(t), B(t+1), A(t+1), B(t+2): 14 younger than what this tile needs
+        asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[2][0]), "+v"(r[2][1]) :: "memory");
+        stage_a(t + 2, (buf + 2) % ST);
+        h8 af[4][2];
+        const char* base = smem + buf * 8192 + frow * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) af[i][s2] = *(const h8*)(base + i * 2048 + (((s2 * 4 + fq) ^ (frow & 7)) * 16));
+        if constexpr (FULL & 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < nblk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r[j][s2], af[i][s2], acc[i][j], 0, 0, 0);
+        } else {
+            for (int i = 0; i < 4; ++i) for (int s2 = 0; s2 < 2; ++s2) asum += af[i][s2];
+            for (int j = 0; j < 3; ++j) { asum += r[j][0]; asum += r[j][1]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(t + 3, r);
+    };
+    for (int t = 0; t < total; t += 3) {
+        body(t, 0, b[0]);
+        body(t + 1, 1, b[1]);
+        body(t + 2, 2, b[2]);
+    }
+    float a = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) a += acc[i][j][0];
+    a += (float)asum[0] + (float)b[0][0][0][0] + (float)b[1][0][0][0] + (float)b[2][0][0][0];
+    __syncthreads();
+    a += ((const float*)smem)[tid];
+    if (a == 123.456f) sink[0] = a;
+}
+
+template <int FULL>
+void run_bd(const char* name, const f16* A, const f16* W, int K, float* sink) {
+    const int reps = 42, grid = 256;
+    const size_t lds = 90 * 1024;
+    auto k = bd_kernel<FULL>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, A, W, K, reps, sink);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, A, W, K, reps, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us_tile = ms * 1e3 / iters / ((double)(K / 64) * reps);
+    printf("%-60s %6.3f us per K tile\n", name, us_tile);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) printf("  error: %s\n", hipGetErrorString(e));
+}
+
 template <int MODE, int NW, int ST, int TPB = 1>
 void run(const char* name, const f16* A, const f16* W, int K, float* sink, int xcd_rows, int grid) {
     const int reps = 40;
@@ -238,6 +348,15 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < h.size(); ++i) h[i] = (f16)((float)(rand() % 2001 - 1000) * 1e-3f);
     hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
     hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+    if (argc > 1 && argv[1][0] == 'b') {   // weight operand straight into registers (no LDS): does the K tile get cheaper than the 0.43 us of the shipped loop?
+        run<7, 8, 3>("shipped form: 4 loaders + 4 waves x (14 reads + 20 mfma16)", A, W, K, sink, 1, 256);
+        run_bd<0>("B direct: A by LDS-DMA + reads, B to registers, no MFMA", A, W, K, sink);
+        run_bd<1>("B direct: the same with the MFMAs (24 / 16 per wave)", A, W, K, sink);
+        run_bd<2>("B direct, fragment-major weights: loads + reads, no MFMA", A, W, K, sink);
+        run_bd<3>("B direct, fragment-major weights: with the MFMAs", A, W, K, sink);
+        run_bd<3>("B direct, fragment-major weights: again", A, W, K, sink);
+        return 0;
+    }
     if (argc > 1) {   // loader / compute co-issue: what slows the LDS-DMA issue of the loader-wave GEMM (880 cycles per K tile against 480 here)?
         run<0, 4, 3>("LDS-DMA 4 waves ring3 barrier (loaders alone)", A, W, K, sink, 1, 256);
         run<4, 8, 3>("4 loaders + 4 waves x 20 mfma16x16x32", A, W, K, sink, 1, 256);
