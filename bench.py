@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end pipe(...) call (images/s measured)")
     ap.add_argument("--no-inkernel-prefetch", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no encoder/previewer overlap)")
+    ap.add_argument("--rows", type=int, default=2, choices=[1, 2],
+                    help="1: the step WITHOUT classifier-free guidance (one UNet row per image) -- a timing experiment on per-launch "
+                         "overheads, not the BASELINE workload; the JSON line says so")
     ap.add_argument("--config", type=int, default=1, choices=[1, 4],
                     help="BASELINE.json configs index: 1 = the metric's own workload (default); 4 = LCM single-step previewer "
                          "restoration, 4 images per GPU, fp8-E4M3 weights on the linear layers (a parity-test configuration, "
@@ -219,9 +222,13 @@ def main():
     npe = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g)
     pooled, npooled = torch.randn(B, cfg.pooled_dim, generator=g), torch.randn(B, cfg.pooled_dim, generator=g)
     img = torch.randn(2, B, cfg.resampler.seq_len, cfg.resampler.embedding_dim, generator=g)
-    ctx, pl = torch.cat([npe, pe]), torch.cat([npooled, pooled])
+    rep = args.rows
+    if rep == 1:
+        ctx, pl, img, guidance = pe, pooled, img[1:], 1.0
+    else:
+        ctx, pl = torch.cat([npe, pe]), torch.cat([npooled, pooled])
     px = Hl * 8
-    time_ids = torch.tensor([[px, px, 0, 0, px, px]], dtype=torch.float32).repeat(2 * B, 1)
+    time_ids = torch.tensor([[px, px, 0, 0, px, px]], dtype=torch.float32).repeat(rep * B, 1)
     st = pipe._unet.prepare(ctx, pl, time_ids, pipe._unet.resampler(img), Hl, Hl)
     st_prev = pipe._unet_prev.prepare(ctx, pl, time_ids, pipe._unet_prev.resampler(img), Hl, Hl)
     st_agg = pipe._agg.prepare(pl, time_ids, Hl, Hl)
@@ -229,9 +236,9 @@ def main():
     pipe.scheduler.set_timesteps(n_steps_sched)
     ts = [int(t) for t in pipe.scheduler.timesteps]
     lqd = lq.to(dev)
-    loop = _DenoiseLoop(pipe, B, 2, Hl, Hl, st, st_prev, st_agg, lqd, None, lcm)
+    loop = _DenoiseLoop(pipe, B, rep, Hl, Hl, st, st_prev, st_agg, lqd, None, lcm)
     x = pipe.scheduler.add_noise(lqd, torch.randn(lq.shape, generator=g).to(dev), torch.tensor([ts[0]] * B)).contiguous()
-    scale_rows = torch.ones(2 * B)
+    scale_rows = torch.ones(rep * B)
     setup_s = time.time() - t0
     log(f"prepared ({setup_s:.1f} s); warmup")
 
@@ -347,7 +354,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 (fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {args.size}x{args.size}, batch 1/GPU, cfg 7.0 (2 rows), 30-step DDIM "
                                    f"timetable, preview_start 0, full SDXL+TA-IP UNet x2 + Aggregator per step"
-                                   + (" [TINY DEBUG GEOMETRY]" if args.tiny else ""),
+                                   + (" [TINY DEBUG GEOMETRY]" if args.tiny else "")
+                                   + (" [EXPERIMENT --rows 1: NO classifier-free guidance, not the BASELINE workload]" if args.rows == 1 else ""),
                        "images_per_gpu": B, "latent": [Hl, Hl], "weight_elements": n_params, "graph": not args.no_graph,
                        # SURVEY 8d's model at the metric's 1024^2; the other resolutions are parity-test configurations whose step was
                        # counted once by hand: no figure is claimed for sizes without one

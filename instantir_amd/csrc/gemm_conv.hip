@@ -61,12 +61,20 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | 0x0F70 | ((n >> 4) << 14); } 
 // One asm statement with a memory clobber: no LDS access may be scheduled across it.
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm_and_barrier() {
+#ifdef IIR_DBG_NO_BARRIER
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
 }
 
 template <int N>
 __device__ __forceinline__ void wait_vm_and_barrier() {
+#ifdef IIR_DBG_NO_BARRIER      // (timing experiment of DESIGN.md 5.10, results wrong: the K loop's barrier removed)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
 }
 
 // W8 (BASELINE configs[4]: "fp8 MFMA weights"): the weight operand is fp8-E4M3 with one fp32 scale per output channel.  Its
@@ -200,17 +208,30 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         for (int i = 0; i < (CONV ? A_INST : 0); ++i) cv_ptr[i] += cv_inc[i] ? cv_c0 : 0;
     };
 
+    // (timing experiments of DESIGN.md 5.10, results wrong: -DIIR_DBG_THIN_A / _B stage 4 bytes per lane instead of 16 for the
+    // activation / weight pieces after the first tile -- same instruction count and waits, a quarter of the bytes)
+#ifdef IIR_DBG_THIN_A
+#define GLDS_A(src, dst) do { if (kt > kt0_dbg) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src), (LDS_AS void*)(dst), 4, 0, 0); else glds16(src, dst); } while (0)
+#else
+#define GLDS_A(src, dst) glds16(src, dst)
+#endif
+#ifdef IIR_DBG_THIN_B
+#define GLDS_B(src, dst) do { if (kt > kt0_dbg) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src), (LDS_AS void*)(dst), 4, 0, 0); else glds16(src, dst); } while (0)
+#else
+#define GLDS_B(src, dst) glds16(src, dst)
+#endif
+    const int kt0_dbg = 2;
     auto stage = [&](int kt, int buf) {
         f16* as = As + buf * BM * BK;
         f16* bs = Bs + buf * BN * BK;
         const int k0 = kt * BK;
         if (!CONV) {
 #pragma unroll
-            for (int i = 0; i < A_INST; ++i) glds16(a_src[i] + k0, as + (i * NW + wave) * 8 * BK);
+            for (int i = 0; i < A_INST; ++i) GLDS_A(a_src[i] + k0, as + (i * NW + wave) * 8 * BK);
         } else {
 #pragma unroll
             for (int i = 0; i < A_INST; ++i) {
-                glds16(cv_ptr[i], as + (i * NW + wave) * 8 * BK);
+                GLDS_A(cv_ptr[i], as + (i * NW + wave) * 8 * BK);
                 cv_ptr[i] += cv_inc[i];
             }
             cv_c0 += BK;
@@ -222,7 +243,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         if (!W8) {
 #pragma unroll
             for (int i = 0; i < B_INST; ++i) {
-                if (B_GROUPS % NW == 0 || i * NW + wave < B_GROUPS) glds16(b_src[i] + k0, bs + (i * NW + wave) * 8 * BK);
+                if (B_GROUPS % NW == 0 || i * NW + wave < B_GROUPS) GLDS_B(b_src[i] + k0, bs + (i * NW + wave) * 8 * BK);
                 else     // (8-wave builds of the 160-wide tiles: 20 row groups over 8 waves) one 4-byte touch keeps the counted waits uniform
                     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g.W, (LDS_AS void*)(smem + RING_BYTES + wave * 256), 4, 0, 0);
             }
@@ -307,6 +328,13 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     auto frags = [&](int buf, int s, E8 (&af)[MI], BF (&bf)[NI]) {
         const char* as = (const char*)(As + buf * BM * BK);
         const char* bs = (const char*)Bs + buf * B_STAGE_BYTES;
+#ifdef IIR_DBG_THIN_READS      // (timing experiment of DESIGN.md 5.10, results wrong: two fragment reads per half step instead of MI + NI)
+        af[0] = *(const E8*)(as + a_off[s]);
+        bf[0] = *(const BF*)(bs + b_off[s]);
+        for (int i = 1; i < MI; ++i) af[i] = af[0];
+        for (int j = 1; j < NI; ++j) bf[j] = bf[0];
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = *(const E8*)(as + a_off[s] + i * 16 * 128);
 #pragma unroll

@@ -21,7 +21,7 @@ constexpr int BM = 64, BN = 160, ROWS = BM + BN;   // 224 rows of 128 B per K ti
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE, int NW, int ST, int TPB = 1>
+template <int MODE, int NW, int ST, int TPB = 1, int LPWO = 0>
 __global__ __launch_bounds__(NW * 64) void fill_kernel(const f16* __restrict__ A, const f16* __restrict__ W, int K, int reps, float* sink, int xcd_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NW * 64) void fill_kernel(const f16* __restrict__ A
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
         typedef float f4 __attribute__((ext_vector_type(4)));
         typedef float f16v __attribute__((ext_vector_type(16)));
-        constexpr int LPW = PIECES / 4;     // 7 pieces per loader wave
+        constexpr int LPW = LPWO ? LPWO : PIECES / 4;     // 7 pieces per loader wave (LPWO: fewer -- the conv-halo question: what is a smaller fill worth?)
         constexpr int GB = TPB * ROWS * 128; // bytes of one ring slot (TPB tiles)
         const int groups = total / TPB;
         if (wave < 4) {
@@ -315,11 +315,11 @@ void run_bd(const char* name, const f16* A, const f16* W, int K, float* sink) {
     if (e != hipSuccess) printf("  error: %s\n", hipGetErrorString(e));
 }
 
-template <int MODE, int NW, int ST, int TPB = 1>
+template <int MODE, int NW, int ST, int TPB = 1, int LPWO = 0>
 void run(const char* name, const f16* A, const f16* W, int K, float* sink, int xcd_rows, int grid) {
     const int reps = 40;
     const size_t lds = (size_t)(MODE == 1 ? 2 : ST) * TPB * ROWS * 128 > 90 * 1024 ? (size_t)ST * TPB * ROWS * 128 : 90 * 1024;   // >= 90 KiB: one workgroup per CU
-    auto k = fill_kernel<MODE, NW, ST, TPB>;
+    auto k = fill_kernel<MODE, NW, ST, TPB, LPWO>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -348,6 +348,15 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < h.size(); ++i) h[i] = (f16)((float)(rand() % 2001 - 1000) * 1e-3f);
     hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
     hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+    if (argc > 1 && argv[1][0] == 'h') {   // same compute (14 reads + 20 MFMA per wave and K tile), fewer bytes filled per K tile
+        run<7, 8, 3, 1, 7>("reads + mfma16, 28 KiB filled per K tile (shipped)", A, W, K, sink, 1, 256);
+        run<7, 8, 3, 1, 6>("reads + mfma16, 24 KiB filled per K tile", A, W, K, sink, 1, 256);
+        run<7, 8, 3, 1, 5>("reads + mfma16, 20 KiB filled per K tile", A, W, K, sink, 1, 256);
+        run<7, 8, 3, 1, 4>("reads + mfma16, 16 KiB filled per K tile", A, W, K, sink, 1, 256);
+        run<7, 8, 3, 1, 2>("reads + mfma16,  8 KiB filled per K tile", A, W, K, sink, 1, 256);
+        run<7, 8, 3, 1, 7>("reads + mfma16, 28 KiB filled per K tile (again)", A, W, K, sink, 1, 256);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'b') {   // weight operand straight into registers (no LDS): does the K tile get cheaper than the 0.43 us of the shipped loop?
         run<7, 8, 3>("shipped form: 4 loaders + 4 waves x (14 reads + 20 mfma16)", A, W, K, sink, 1, 256);
         run_bd<0>("B direct: A by LDS-DMA + reads, B to registers, no MFMA", A, W, K, sink);
