@@ -148,6 +148,7 @@ class _Net:
         self._skws = None
         self._warena = None
         self.inkernel_prefetch = True
+        self.arena_gen = 0
         self.fuse_qkv = os.environ.get("IIR_FUSE_QKV", "1") != "0"
         # LayerNorm folded into the GEMMs either side of it (ops.LnFold; iir_gemm_desc.ln_stats_out / ln_stats_in): not with fp8
         # operands (the activation would be rounded to 3 mantissa bits BEFORE its row mean is removed)
@@ -283,6 +284,7 @@ class _Net:
     def _size_arena(self, fn):
         """Dry-run `fn` (launches skipped) to find the arena high-water mark, then allocate it."""
         self.arena.buf, self.arena.off, self.arena.high = None, 0, 0
+        self.arena_gen = getattr(self, "arena_gen", 0) + 1        # launch sequences captured on the previous arena are stale
         self.o = _NullOps()
         plain = self.w
         first = not self.units

@@ -135,6 +135,7 @@ class InstantIRPipeline:
         self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2               # callables: list[str] -> (B,77) int64 ids
         self._unet = self._unet_prev = self._agg = self._unet_prev8 = None
         self._graphs = {}
+        self._loop_cache = None                     # (key, _DenoiseLoop) of the last call: see _loop_for
         self.use_graphs = True
         self.overlap_streams = True
         self.overlap_sft = os.environ.get("IIR_OVERLAP_SFT", "1") != "0"     # shallow SFT heads beside the decoder's first up block
@@ -259,6 +260,24 @@ class InstantIRPipeline:
             if self._agg_sd is None:
                 self._agg_sd = self.aggregator.from_unet()
             self._agg = HipAggregator(self.cfg, self._agg_sd, self.device)
+
+    def _loop_for(self, B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler, guidance_rescale):
+        """The step's buffers and captured hipGraphs are kept from one call to the next: a second image of the same geometry,
+        through the same engines, re-uses them (its hoisted K / V, embeddings and LQ latent are copied into the captured
+        tensors) instead of paying the warm-up step, the capture and the graph instantiation again (~0.1 s of a 1.9 s call
+        at 1024^2).  Anything the captured launches depend on is part of the key; `IIR_LOOP_CACHE=0` switches it off."""
+        nets = (self._unet, self._unet_prev, self._agg)
+        key = (B, rep, Hl, Wl, reference_latents is not None, float(guidance_rescale or 0.0), self.use_graphs, self.overlap_streams,
+               self.overlap_sft, tuple(None if n is None else (id(n), n.arena_gen, n.inkernel_prefetch, n.gn_fuse) for n in nets))
+        cached = self._loop_cache
+        if cached is not None and cached[0] == key and os.environ.get("IIR_LOOP_CACHE", "1") != "0":
+            if cached[1].adopt(st, st_prev, st_agg, lq, reference_latents, previewer_scheduler):
+                return cached[1]
+        self._loop_cache = None                      # drop the old graphs before building the new ones
+        loop = _DenoiseLoop(self, B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler,
+                            guidance_rescale=guidance_rescale)
+        self._loop_cache = (key, loop)
+        return loop
 
     # ---- input checks (pipelines/sdxl_instantir.py:749-864, the conditions that apply to tensor inputs) ----
     def check_inputs(self, prompt, prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds,
@@ -592,8 +611,7 @@ class InstantIRPipeline:
             x = latents.to(dev, torch.float32) * self.scheduler.init_noise_sigma
         x = x.contiguous()
 
-        loop = _DenoiseLoop(self, B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler,
-                            guidance_rescale=guidance_rescale)
+        loop = self._loop_for(B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler, guidance_rescale)
         preview_row = []
         preview_factor = torch.ones(B)
         compound = None            # per-image scale the Aggregator's (persistent, raw) outputs currently carry
@@ -673,6 +691,32 @@ class InstantIRPipeline:
         return StableDiffusionXLPipelineOutput(images=image_out)
 
 
+def _copy_state(dst, src):
+    """Refresh a `prepare()` state in place (same structure, shapes and dtypes) so that launch sequences captured on `dst`'s
+    tensors see `src`'s values.  `ada_jobs` is a device table of pointers into `dst`'s own tensors and stays.  False = the
+    two states differ in structure: the caller builds a new loop."""
+    if dst is None or src is None:
+        return dst is None and src is None
+    if len(dst) != len(src):
+        return False
+    for k, v in src.items():
+        if k not in dst:
+            return False
+        d = dst[k]
+        if k == "ada_jobs":
+            continue
+        if isinstance(v, dict):
+            if not isinstance(d, dict) or not _copy_state(d, v):
+                return False
+        elif isinstance(v, torch.Tensor):
+            if not isinstance(d, torch.Tensor) or d.shape != v.shape or d.dtype != v.dtype or d.device != v.device:
+                return False
+            d.copy_(v)
+        elif d != v:
+            return False
+    return True
+
+
 class _DenoiseLoop:
     """Device buffers + (optionally hipGraph-captured) launch sequences of one denoising step.
     Three phases exist (pipelines/sdxl_instantir.py:1542-1616): "preview" (UNet+LoRA -> LCM preview
@@ -713,6 +757,21 @@ class _DenoiseLoop:
         self.res_scale = self.sc_dev[R + 12:]
         self.graphs = {}
         self.side = None
+
+    def adopt(self, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler):
+        """Re-use this loop -- its buffers and captured graphs -- for another call of the same geometry: the new call's hoisted
+        state is copied into the tensors the graphs were captured on.  False when the states do not line up."""
+        if (self.ref16 is None) != (reference_latents is None):
+            return False
+        if not (_copy_state(self.st, st) and _copy_state(self.st_prev, st_prev) and _copy_state(self.st_agg, st_agg)):
+            return False
+        self.prev_sched = previewer_scheduler
+        ops.pack_latent(lq, self.lq16, rep=self.rep)
+        if self.ref16 is not None:
+            ops.pack_latent(reference_latents.to(self.x_in.device, torch.float32).contiguous(), self.ref16, rep=self.rep)
+        self.previewer_mean = torch.zeros_like(self.x_in)
+        self.cfg_factor.fill_(1.0)
+        return True
 
     def _launch(self, mode, use_noise, want_x0, want_preview):
         p, B, rep = self.p, self.B, self.rep

@@ -396,3 +396,33 @@ def test_adapter_switching_and_lora_scale(env):
         _call(pipe, inp, cross_attention_kwargs={"external_kv": None}, **kw)
     with pytest.raises(ValueError):
         pipe.unet.set_adapter("nope")
+
+
+def test_step_graphs_are_reused_across_calls(env, monkeypatch):
+    """A second image of the same geometry runs on the first call's buffers and captured graphs (its hoisted state is copied
+    in): results must be bit-identical to calls that build everything afresh, in any order of inputs."""
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+    g = torch.Generator().manual_seed(77)
+    inp_b = dict(inp)
+    for k in ("lq", "pe", "pooled", "npe", "npooled", "img", "init_noise"):
+        inp_b[k] = (torch.randn(inp[k].shape, generator=g) * 0.7).half().float()
+    pipe = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    kw = dict(num_inference_steps=4, guidance_scale=7.0)
+    a1 = _call(pipe, inp, **kw)
+    loop = pipe._loop_cache[1]
+    b1 = _call(pipe, inp_b, **kw)
+    assert pipe._loop_cache[1] is loop, "second call of the same geometry built a new loop"
+    a2 = _call(pipe, inp, **kw)
+    assert pipe._loop_cache[1] is loop
+    assert torch.equal(a1, a2) and not torch.equal(a1, b1)
+    # a different number of rows (no classifier-free guidance): a new loop, and back again
+    inp_c = dict(inp, img=inp["img"][1:])
+    c1 = _call(pipe, inp_c, num_inference_steps=4, guidance_scale=1.0)
+    assert pipe._loop_cache[1] is not loop
+    a3 = _call(pipe, inp, **kw)
+    assert torch.equal(a1, a3)
+    monkeypatch.setenv("IIR_LOOP_CACHE", "0")
+    fresh = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    assert torch.equal(_call(fresh, inp_b, **kw), b1)
+    assert torch.equal(_call(fresh, inp_c, num_inference_steps=4, guidance_scale=1.0), c1)
