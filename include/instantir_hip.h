@@ -28,6 +28,7 @@ extern "C" {
 #define IIR_EPI_PLAIN 0 /* C = act(acc + bias + rowbias) + res                                    */
 #define IIR_EPI_GEGLU 1 /* C[:, j] = (acc_v + b_v) * gelu_erf(acc_g + b_g); W rows pair-permuted  */
 #define IIR_EPI_SFT 2   /* C[:, j] = res[:, j] * (acc_gamma + b + 1) + (acc_beta + b)             */
+#define IIR_EPI_XATTN 3 /* C = cross_attention(q = acc + bias, xattn_kv[0], xattn_kv[1]): see iir_gemm_desc.xattn_kv */
 #define IIR_ACT_NONE 0
 #define IIR_ACT_SILU 1
 #define IIR_ACT_GELU 2 /* erf form */
@@ -40,6 +41,12 @@ extern "C" {
 
 #define IIR_DT_F16 0
 #define IIR_DT_BF16 1
+
+typedef struct iir_attn_kv {
+    const void* K; int64_t ldk, k_batch_stride;     /* K[b][t][h*64+d]                               */
+    const void* Vt; int64_t ldvt, vt_batch_stride;  /* Vt[h*64+d][b*vt_batch_stride + t]; rows finite */
+    int32_t Tkv;                                    /*   and readable on [0, roundup8(Tkv))           */
+} iir_attn_kv;
 
 typedef struct iir_gemm_desc {
     const void* A; int64_t lda;    /* [M][K] activations, row stride lda                           */
@@ -78,6 +85,13 @@ typedef struct iir_gemm_desc {
     /* module/min_sdxl.py:242-283,565-595): no separate statistics pass over the tensor                                               */
     void* gn_stats_out;            /* optional (PLAIN epilogue, whole tiles, M % 64 == 0): float2 [M / 64][N] = (mean, M2) of the 64   */
                                    /*   stored values of every channel per 64-row slab; consumed by iir_groupnorm_from_partials       */
+    /* IIR_EPI_XATTN: the Linear is `attn2.to_q` of TA_IPAttnProcessor2_0 (module/ip_adapter/attention_processor.py:1140) with the     */
+    /* softmax scale x log2(e) folded into W / bias by the caller; every workgroup finishes a 64-row x 2-head tile of q and runs the    */
+    /* two SDPA calls + add of :1165,:1185,:1192 on it, so C receives `hidden_states + ip_hidden_states` (before to_out) and q never     */
+    /* goes to memory.  Needs: fp16, N % 128 == 0 (head dimension 64), M % 64 == 0, xattn_tq % 64 == 0, 1 <= Tkv[0] <= 80,             */
+    /* 1 <= Tkv[1] <= 64, ldk / ldvt / batch strides % 8 == 0, no res / rowbias / act / Ct / c_f32 / wscale / *_stats_out / split-K.      */
+    const iir_attn_kv* xattn_kv;   /* [2]: text K / V^T, IP-token K / V^T (layouts as for iir_attention_d64_f16)                       */
+    int32_t xattn_tq;              /* query rows per image (row m belongs to image m / xattn_tq)                                      */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -131,12 +145,6 @@ typedef struct iir_conv_desc {
  * `rowbias`, the residual add :279 as `res`), Downsample2D :601-606, Upsample2D :612-618 (with
  * F.interpolate nearest folded in), conv_in/conv_out :827,912, SFT module/aggregator.py:62-67,76-86. */
 int iir_conv2d_nhwc_f16(const iir_conv_desc* c, void* stream);
-
-typedef struct iir_attn_kv {
-    const void* K; int64_t ldk, k_batch_stride;     /* K[b][t][h*64+d]                               */
-    const void* Vt; int64_t ldvt, vt_batch_stride;  /* Vt[h*64+d][b*vt_batch_stride + t]; rows finite */
-    int32_t Tkv;                                    /*   and readable on [0, roundup8(Tkv))           */
-} iir_attn_kv;
 
 typedef struct iir_attn_desc {
     const void* Q; int64_t ldq, q_batch_stride;     /* Q[b][t][h*64+d]                               */

@@ -467,6 +467,151 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         mma(a1, b1);
     }
 
+    // ---- IIR_EPI_XATTN: `to_q` and the decoupled text / IP cross-attention of
+    // TA_IPAttnProcessor2_0 (module/ip_adapter/attention_processor.py:1140-1192) in one launch.  The 64 x 128 tile is q for 64 rows
+    // of one image and two heads; wave (wm, wn) holds rows 32 wm .. +32 of head wn in its accumulators.  Nothing is re-laid-out:
+    // an accumulator lane (frow, fq) holds q[frow][16 j + 4 fq + t] -- as an MFMA operand that is "8 values of the contraction
+    // index" for ANY consistent order of that index, so the K fragment is read in the same permuted order (two 8-byte pieces
+    // per lane), S = q K^T lands as (row frow, keys 16 kb + 4 fq + t), and P feeds P V the same way with V^T read in matching
+    // key order.  Both softmaxes (text keys, IP keys) are exact two-pass ones over <= 80 / 64 keys held in registers; each is
+    // normalised before P V, so one accumulator sums text and IP outputs (`hidden_states + ip_hidden_states`, :1192, scale 1).
+    // The K / V^T images (72 KiB: exactly the idle ring) are staged by LDS-DMA after the K loop; requesting them into registers at
+    // kernel entry instead (182 VGPRs) measured SLOWER (22.3 vs 20.6 us per level-2 launch).
+    bool xdone = false;
+    if constexpr (BM == 64 && BN == 128 && ST == 3 && !CONV && !W8 && !LW && WAVES_M == 2 && std::is_same<E, f16>::value) {
+    if (g.xa_on) {
+        constexpr int KROWS = 144, KIMG = KROWS * 128, VROW = 288, VIMG = 64 * VROW;     // per head: K image 18 KiB, V^T image 18 KiB
+        static_assert(2 * KIMG + 2 * VIMG <= RING_BYTES, "K / V images of two heads must fit the idle ring");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading the ring
+        const int img = m0 / g.xa_tq, hd0 = n0 >> 6;
+        char* kl = smem;
+        char* vl = smem + 2 * KIMG;
+        const int tk0 = g.xa_tk[0], tk1 = g.xa_tk[1];
+        const int vch0 = (tk0 + 7) >> 3, vch1 = (tk1 + 7) >> 3;               // readable 16-byte chunks of a V^T row
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {          // K rows: [0, 80) text keys, [80, 144) IP keys; rows past Tkv repeat the last key (masked below)
+            const int s = (it * 4 + wave) * 64 + lane, hh = s >= 1152 ? 1 : 0, sl = s - hh * 1152;
+            const int row = sl >> 3, ch = (sl & 7) ^ (row & 7);
+            const bool ip = row >= 80;
+            const int key = ip ? min(row - 80, tk1 - 1) : min(row, tk0 - 1);
+            const f16* src = (ip ? g.xa_k[1] + (long)img * g.xa_kb[1] + (long)key * g.xa_ldk[1]
+                                 : g.xa_k[0] + (long)img * g.xa_kb[0] + (long)key * g.xa_ldk[0]) + (hd0 + hh) * 64 + ch * 8;
+            glds16(src, kl + (it * 4 + wave) * 1024);
+        }
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {          // V^T rows d = 0..63 of each head: 10 chunks of text keys, 8 chunks of IP keys
+            const int s = (it * 4 + wave) * 64 + lane, hh = s >= 1152 ? 1 : 0, sl = s - hh * 1152;
+            const int d = sl / 18, c = sl - d * 18;
+            const bool ip = c >= 10;
+            const int cc = ip ? min(c - 10, vch1 - 1) : min(c, vch0 - 1);
+            const long rowv = (long)((hd0 + hh) * 64 + d);
+            const f16* src = (ip ? g.xa_vt[1] + rowv * g.xa_ldvt[1] + (long)img * g.xa_vb[1]
+                                 : g.xa_vt[0] + rowv * g.xa_ldvt[0] + (long)img * g.xa_vb[0]) + cc * 8;
+            glds16(src, vl + (it * 4 + wave) * 1024);
+        }
+        // q = what the plain epilogue would have stored (LayerNorm fold, bias, fp16 rounding), as MFMA operands
+        typedef E E4v __attribute__((ext_vector_type(4)));
+        E8 qf[MI][2];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float2 rs = g.ln_in ? rowstat[wm * WM + i * 16 + frow] : make_float2(1.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    qf[i][j >> 1][(j & 1) * 4 + t] = (E)fmaf(acc[i][j][t], rs.x, fmaf(rs.y, pre_c1[j][t], (float)pre_c0[j][t]));
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");         // K / V images complete
+        // S = q K^T: 9 key blocks of 16 (5 text, 4 IP), contraction over d in the accumulator's order
+        f32x4 sa[MI][9];
+        const char* kh = kl + wn * KIMG;
+#pragma unroll
+        for (int kb = 0; kb < 9; ++kb) {
+            const int kr = kb * 16 + frow;
+            const char* krow = kh + kr * 128 + (fq & 1) * 8;
+            E8 kf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const E4v lo = *(const E4v*)(krow + (((4 * ks + (fq >> 1)) ^ (kr & 7)) << 4));
+                const E4v hi = *(const E4v*)(krow + (((4 * ks + 2 + (fq >> 1)) ^ (kr & 7)) << 4));
+                for (int t = 0; t < 4; ++t) { kf[ks][t] = lo[t]; kf[ks][4 + t] = hi[t]; }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                z = ET<E>::mfma16(kf[0], qf[i][0], z);
+                sa[i][kb] = ET<E>::mfma16(kf[1], qf[i][1], z);
+            }
+        }
+        // softmax per segment (q carries scale x log2 e: p = exp2(s - max)), normalised, as the P operand of P V
+        E8 pf[MI][5];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+            for (int kb = 0; kb < 9; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int key = (kb < 5 ? kb * 16 : kb * 16 - 80) + fq * 4 + t;
+                    const bool ok = key < (kb < 5 ? tk0 : tk1);
+                    sa[i][kb][t] = ok ? sa[i][kb][t] : -INFINITY;
+                    mx[kb < 5 ? 0 : 1] = fmaxf(mx[kb < 5 ? 0 : 1], sa[i][kb][t]);
+                }
+#pragma unroll
+            for (int sgm = 0; sgm < 2; ++sgm) {
+                mx[sgm] = fmaxf(mx[sgm], __shfl_xor(mx[sgm], 16, 64));
+                mx[sgm] = fmaxf(mx[sgm], __shfl_xor(mx[sgm], 32, 64));
+            }
+            float sm[2] = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 9; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float pv = __builtin_amdgcn_exp2f(sa[i][kb][t] - mx[kb < 5 ? 0 : 1]);     // masked keys: exp2(-inf) = 0
+                    sa[i][kb][t] = pv;
+                    sm[kb < 5 ? 0 : 1] += pv;
+                }
+#pragma unroll
+            for (int sgm = 0; sgm < 2; ++sgm) {
+                sm[sgm] += __shfl_xor(sm[sgm], 16, 64);
+                sm[sgm] += __shfl_xor(sm[sgm], 32, 64);
+                sm[sgm] = __builtin_amdgcn_rcpf(sm[sgm]);
+            }
+#pragma unroll
+            for (int kp = 0; kp < 5; ++kp)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ka = 2 * kp, kb2 = 2 * kp + 1;
+                    pf[i][kp][t] = (E)(sa[i][ka][t] * sm[ka < 5 ? 0 : 1]);
+                    pf[i][kp][4 + t] = kb2 < 9 ? (E)(sa[i][kb2 < 9 ? kb2 : 8][t] * sm[kb2 < 5 ? 0 : 1]) : (E)0.f;
+                }
+        }
+        // O = P V: contraction over keys in the order P holds them (key column 16 kb + 4 fq + t: IP keys start at column 80)
+        const char* vh = vl + wn * VIMG;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const char* vrow = vh + (j * 16 + frow) * VROW + fq * 8;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kp = 0; kp < 5; ++kp) {
+                const E4v lo = *(const E4v*)(vrow + (2 * kp) * 32);
+                const E4v hi = *(const E4v*)(vrow + (kp < 4 ? 2 * kp + 1 : 8) * 32);       // (the ninth block's partner: P is zero there)
+                E8 vf;
+                for (int t = 0; t < 4; ++t) { vf[t] = lo[t]; vf[4 + t] = hi[t]; }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = ET<E>::mfma16(vf, pf[i][kp], acc[i][j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {            // the tile now holds finished values: phase 1 adds nothing
+            pre_c1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) pre_c0[j][t] = (E)0.f;
+        }
+        xdone = true;
+    }
+    }
+
     // ---- epilogue, phase 1: registers -> LDS.  A lane holds row m = ..+frow and 4 consecutive columns n = ..+4*fq+{0..3};
     // stored straight to memory that is 16 rows x 32 B per instruction (16 B for the paired epilogues), which made the
     // write-out -- not the K loop -- the fixed cost of every launch.  So the finished fp16 tile (bias / row bias /
@@ -535,7 +680,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     for (int i = 0; i < MI; ++i) {
         lrs[i] = wm * WM + i * 16 + frow;                  // row inside the tile
         ms[i] = min(m0 + lrs[i], g.M - 1);                 // tail rows: computed from clamped operands, dropped in phase 2
-        rss[i] = g.ln_in ? rowstat[lrs[i]] : make_float2(1.f, 0.f);
+        rss[i] = (g.ln_in && !xdone) ? rowstat[lrs[i]] : make_float2(1.f, 0.f);
     }
     if (!paired) {
 #pragma unroll
@@ -964,6 +1109,7 @@ bool gemm8_auto(const Geo& g, bool conv) {
 }
 
 int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
+    if (g.xa_on) return conv ? IIR_EINVAL : launch<64, 128, 3>(g, false, stream);      // to_q + cross-attention: the head-aligned 64 x 128 tile, two workgroups per CU
     // Two-slice split-K, taken only when the caller hands over a workspace: two 128x160 workgroups per tile each take half of
     // K and the last one to finish reduces (see the kernel).  Meant for long-K problems too small to fill the chip with
     // 128x160 tiles (M x N = 2048 x 1280 at K = 5120 / 11520); MEASURED SLOWER than one 64x160 workgroup per CU over all
@@ -1091,6 +1237,7 @@ extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
 extern "C" int iir_gemm_resolve_tile(const iir_gemm_desc* d) {
     Geo g{};
     if (fill_gemm_geo(d, g) != IIR_OK) return -1;
+    if (g.xa_on) return 93;
     if (d->tile != 0) return d->tile;
     if (gemm8_auto(g, false)) return 91;
     return pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
@@ -1103,10 +1250,26 @@ static int fill_gemm_geo(const iir_gemm_desc* d, Geo& g) {
     if (d->epi != IIR_EPI_PLAIN && (d->N % 16)) return IIR_EINVAL;
     if (d->epi == IIR_EPI_SFT && !d->res) return IIR_EINVAL;
     if (d->rowbias && d->rows_per_rb <= 0) return IIR_EINVAL;
+    if (d->epi < IIR_EPI_PLAIN || d->epi > IIR_EPI_XATTN) return IIR_EINVAL;
+    if (d->epi == IIR_EPI_XATTN) {
+        const iir_attn_kv* kv = d->xattn_kv;
+        if (!kv || d->dtype != IIR_DT_F16 || d->N % 128 || d->M % 64 || d->xattn_tq <= 0 || d->xattn_tq % 64 || d->M % d->xattn_tq) return IIR_EINVAL;
+        if (d->res || d->rowbias || d->act || d->Ct || d->c_f32 || d->wscale || d->ln_stats_out || d->gn_stats_out || d->splitk_ws) return IIR_EINVAL;
+        if (d->ldc % 8 || (uintptr_t)d->C % 16 || (d->tile != 0 && d->tile != 93)) return IIR_EINVAL;
+        if (kv[0].Tkv < 1 || kv[0].Tkv > 80 || kv[1].Tkv < 1 || kv[1].Tkv > 64) return IIR_EINVAL;
+        for (int sgm = 0; sgm < 2; ++sgm) {
+            if (!kv[sgm].K || !kv[sgm].Vt || (uintptr_t)kv[sgm].K % 16 || (uintptr_t)kv[sgm].Vt % 16) return IIR_EINVAL;
+            if (kv[sgm].ldk % 8 || kv[sgm].k_batch_stride % 8 || kv[sgm].ldvt % 8 || kv[sgm].vt_batch_stride % 8) return IIR_EINVAL;
+            g.xa_k[sgm] = (const f16*)kv[sgm].K; g.xa_ldk[sgm] = kv[sgm].ldk; g.xa_kb[sgm] = kv[sgm].k_batch_stride;
+            g.xa_vt[sgm] = (const f16*)kv[sgm].Vt; g.xa_ldvt[sgm] = kv[sgm].ldvt; g.xa_vb[sgm] = kv[sgm].vt_batch_stride;
+            g.xa_tk[sgm] = kv[sgm].Tkv;
+        }
+        g.xa_on = 1; g.xa_tq = d->xattn_tq;
+    }
     g.A = (const f16*)d->A; g.lda = d->lda; g.W = (const f16*)d->W; g.C = (f16*)d->C; g.ldc = d->ldc;
     g.M = d->M; g.N = d->N; g.K = d->K;
     g.bias = (const f16*)d->bias; g.rowbias = (const f16*)d->rowbias; g.ldrb = d->ldrb; g.rows_per_rb = d->rows_per_rb;
-    g.res = (const f16*)d->res; g.ldr = d->ldr; g.epi = d->epi; g.act = d->act;
+    g.res = (const f16*)d->res; g.ldr = d->ldr; g.epi = d->epi == IIR_EPI_XATTN ? IIR_EPI_PLAIN : d->epi; g.act = d->act;      // (the tile leaves the XATTN epilogue as a plain one)
     g.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     g.pf = (const char*)d->prefetch; g.pf_lines = d->prefetch ? (int)(d->prefetch_bytes / 128) : 0;
     finish_geo(g);

@@ -55,6 +55,12 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     float* gn_out;                  // GroupNorm statistics of the rows this launch writes: [M / 64][N] (mean, M2) per 64-row slab and channel
     int st_wt;                      // write the output through to memory (sc1 stores): nothing is left dirty in the L2s for the end-of-kernel write-back
     const float* ln_colsum;         //   s[n] = sum_k W[n][k] (fp32): y = rstd * (x . w_n) - rstd * mean * s[n] (+ bias, which carries W . beta)
+    // IIR_EPI_XATTN (64 x 128 tile): the finished tile is a q projection (two heads x 64 rows, scale x log2 e folded in by the caller);
+    // the workgroup runs the text + IP cross-attention of its rows and heads on it and stores the attention output instead
+    int xa_on, xa_tq;               // xa_tq: query rows per image (tile rows never straddle an image: xa_tq % 64 == 0)
+    const f16* xa_k[2]; long xa_ldk[2], xa_kb[2];       // K[img][t][head * 64 + d]   (segment 0: text, 1: IP tokens)
+    const f16* xa_vt[2]; long xa_ldvt[2], xa_vb[2];     // Vt[head * 64 + d][img * vb + t], readable on [0, roundup8(Tkv))
+    int xa_tk[2];                   // 1 <= Tkv[0] <= 80, 1 <= Tkv[1] <= 64
 };
 
 // gemm8.hip: 256 x BN tile, 8 waves, two-tile-deep LDS-DMA pipeline (BN = 320 or 256).  Returns IIR_EINVAL when the launch is

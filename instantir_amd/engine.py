@@ -156,6 +156,7 @@ class _Net:
         # GroupNorm statistics from the launch that produces the GroupNorm's input (ops.gemm / conv2d `gn_out=`, round 3): the
         # producer tags its output tensor with the partials, the GroupNorm that consumes it skips its statistics pass
         self.gn_fuse = os.environ.get("IIR_GN_FUSE", "1") != "0"
+        self.xattn_fuse = os.environ.get("IIR_XATTN_FUSE", "1") != "0"      # attn2.to_q + cross-attention as one launch
         self._pack_encoder(sd)
 
     # ---- weight packing ---------------------------------------------------------------------
@@ -440,18 +441,25 @@ class _Net:
         # -- decoupled cross-attention (TA_IPAttnProcessor2_0, attention_processor.py:1140-1195)
         if self.cross:
             q = qk[:, :C]
-            if fold:
-                o.gemm(h, w[p + ".attn2.to_q.lnw"], q, bias=w[p + ".attn2.to_q.lnb"], prefetch=self._pf(w[p + ".attn2.to_q.lnw"]),
-                       ln_in=(lnst, w[p + ".attn2.to_q.lncs"], 1e-5))
-            else:
-                o.layernorm(h, n, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
-                o.gemm(n, w[p + ".attn2.to_q.w"], q, prefetch=self._pf(w[p + ".attn2.to_q.w"]))
             cfg = self.cfg
             nip, ipad = cfg.num_ip_tokens, (cfg.num_ip_tokens + 7) // 8 * 8
             kv = st["kv"][p]
             ipk, ipvt = kv["ipk"], kv["ipvt"]          # adaLN'd for this step by the batched launch in _embeddings
-            o.attention(q, a, [(kv["tk"], cfg.text_len, kv["tvt"], kv["tpad"], cfg.text_len), (ipk, nip, ipvt, ipad, nip)],
-                        R, heads, T, q_prescaled=True)
+            segs = [(kv["tk"], cfg.text_len, kv["tvt"], kv["tpad"], cfg.text_len), (ipk, nip, ipvt, ipad, nip)]
+            wq = w[p + (".attn2.to_q.lnw" if fold else ".attn2.to_q.w")]
+            # to_q and the text / IP cross-attention in ONE launch (IIR_EPI_XATTN): every workgroup finishes a 64-row x 2-head
+            # tile of q and attends with it; q never goes to memory and 174 launches per step disappear
+            fuse = (self.xattn_fuse and cfg.head_dim == 64 and C % 128 == 0 and T % 64 == 0 and cfg.text_len <= 80 and nip <= 64 and h.dtype == F16
+                    and not isinstance(wq, ops.Fp8Weight))
+            if not fold:
+                o.layernorm(h, n, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
+            src = h if fold else n
+            kw = dict(bias=w[p + ".attn2.to_q.lnb"], ln_in=(lnst, w[p + ".attn2.to_q.lncs"], 1e-5)) if fold else {}
+            if fuse:
+                o.gemm(src, wq, a, prefetch=self._pf(wq), epi=ops.EPI_XATTN, xattn=(segs, T), **kw)
+            else:
+                o.gemm(src, wq, q, prefetch=self._pf(wq), **kw)
+                o.attention(q, a, segs, R, heads, T, q_prescaled=True)
             o.gemm(a, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h,
                    prefetch=self._pf(w[p + ".attn2.to_out.0.w"]), ln_out=lnst)
         # -- GEGLU feed-forward (module/min_sdxl.py:502-528)

@@ -14,8 +14,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinstantir_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "instantir_hip.h")
 
-EPI_PLAIN, EPI_GEGLU, EPI_SFT = 0, 1, 2
+EPI_PLAIN, EPI_GEGLU, EPI_SFT, EPI_XATTN = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3
+
+
+class AttnKV(C.Structure):
+    _fields_ = [
+        ("K", C.c_void_p), ("ldk", C.c_int64), ("k_batch_stride", C.c_int64),
+        ("Vt", C.c_void_p), ("ldvt", C.c_int64), ("vt_batch_stride", C.c_int64),
+        ("Tkv", C.c_int32),
+    ]
 
 
 class GemmDesc(C.Structure):
@@ -38,6 +46,7 @@ class GemmDesc(C.Structure):
         ("ln_stats_out", C.c_void_p), ("ln_stats_in", C.c_void_p), ("ln_parts", C.c_int32), ("ln_part_cols", C.c_int32),
         ("ln_eps", C.c_float), ("ln_colsum", C.c_void_p),
         ("gn_stats_out", C.c_void_p),
+        ("xattn_kv", C.POINTER(AttnKV)), ("xattn_tq", C.c_int32),
     ]
 
 
@@ -60,14 +69,6 @@ class ConvDesc(C.Structure):
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("dtype", C.c_int32),
         ("gn_stats_out", C.c_void_p),
-    ]
-
-
-class AttnKV(C.Structure):
-    _fields_ = [
-        ("K", C.c_void_p), ("ldk", C.c_int64), ("k_batch_stride", C.c_int64),
-        ("Vt", C.c_void_p), ("ldvt", C.c_int64), ("vt_batch_stride", C.c_int64),
-        ("Tkv", C.c_int32),
     ]
 
 

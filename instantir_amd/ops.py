@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_SFT  # noqa: F401
+from .lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_SFT, EPI_XATTN  # noqa: F401
 
 
 def _stream():
@@ -175,12 +175,14 @@ def _chk_gn_out(gn_out, M, N):
 
 
 def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PLAIN, act=ACT_NONE, out_scale=1.0,
-         tile=0, prefetch=None, splitk_ws=None, out_t=None, wscale=None, ln_out=None, ln_in=None, gn_out=None):
+         tile=0, prefetch=None, splitk_ws=None, out_t=None, wscale=None, ln_out=None, ln_in=None, gn_out=None, xattn=None):
     """out = epi(a @ w.T).  a (M,K) view, w (N,K) contiguous, out (M,N) view ((M,N/2) for paired epilogues).
     out_t = (Ct, tr_from): output columns >= tr_from go, transposed, to Ct[n - tr_from, m]; `out` then is (M, tr_from).
     wscale (fp32 (N,)): `w` holds fp8-E4M3 bytes (torch.float8_e4m3fn / uint8) with that per-row scale (fp8 MFMA).
     ln_out (fp32 (parts, M, 2), parts = ln_parts(M, N, K)): also leave LayerNorm partials of the rows written.
-    ln_in = (partials (parts, M, 2) fp32, colsum (N,) fp32, eps): `a` holds raw rows, `w` / `bias` are an `LnFold`'s."""
+    ln_in = (partials (parts, M, 2) fp32, colsum (N,) fp32, eps): `a` holds raw rows, `w` / `bias` are an `LnFold`'s.
+    xattn = (kv, Tq) with epi = EPI_XATTN: `w` is a cross-attention q projection with `attn_q_factor()` folded in; `out` receives the
+    text + IP cross-attention output of those queries (kv: two tuples as for `attention`, Tq: query rows per image)."""
     dt = a.dtype
     if isinstance(w, Fp8Weight):
         w, wscale = w.q, w.scale
@@ -204,7 +206,7 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
     N = w.shape[0]
     if w.shape[1] != K or not w.is_contiguous():
         raise ValueError("w must be contiguous (N,K) with K matching a")
-    n_out = (N if epi == EPI_PLAIN else N // 2) if out_t is None else out_t[1]
+    n_out = (N if epi in (EPI_PLAIN, EPI_XATTN) else N // 2) if out_t is None else out_t[1]
     if out.shape != (M, n_out):
         raise ValueError(f"out shape {tuple(out.shape)} != {(M, n_out)}")
     d = L.GemmDesc()
@@ -238,7 +240,23 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
         if colsum.dtype != torch.float32 or colsum.numel() != N or not colsum.is_contiguous():
             raise ValueError("ln_in colsum: contiguous fp32 (N,)")
         d.ln_stats_in, d.ln_colsum, d.ln_parts, d.ln_part_cols, d.ln_eps = part.data_ptr(), colsum.data_ptr(), part.shape[0], K // part.shape[0], eps
-    if tile == 0:       # the library decides; resolve the same choice here only to NAME the launch for the profiler
+    kv_keep = None
+    if (epi == EPI_XATTN) != (xattn is not None):
+        raise ValueError("epi = EPI_XATTN goes with xattn = (kv, Tq)")
+    if xattn is not None:
+        kvs, tq = xattn
+        if len(kvs) != 2:
+            raise ValueError("xattn: two K / V^T segments (text, IP tokens)")
+        kv_keep = (L.AttnKV * 2)()
+        for i, (k, k_rows, vt, vbs, tkv) in enumerate(kvs):
+            _chk2d(k, "k"); _chk2d(vt, "vt")
+            kv_keep[i].K, kv_keep[i].ldk, kv_keep[i].k_batch_stride = k.data_ptr(), k.stride(0), k_rows * k.stride(0)
+            kv_keep[i].Vt, kv_keep[i].ldvt, kv_keep[i].vt_batch_stride = vt.data_ptr(), vt.stride(0), vbs
+            kv_keep[i].Tkv = tkv
+        d.xattn_kv, d.xattn_tq = kv_keep, tq
+    if xattn is not None:
+        tile = 93
+    elif tile == 0:       # the library decides; resolve the same choice here only to NAME the launch for the profiler
         tile = 4 if splitk_ws is not None and L.load().iir_gemm_uses_splitk(M, N, K, splitk_ws.numel()) else auto_tile(M, N, epi != EPI_PLAIN, K)
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
@@ -250,12 +268,15 @@ def gemm(a, w, out, bias=None, rowbias=None, rows_per_rb=1, res=None, epi=EPI_PL
         if ct.shape[0] < N - tr_from or ct.shape[1] < M:
             raise ValueError("out_t must hold (N - tr_from, M)")
         d.Ct, d.ldct, d.tr_from = ct.data_ptr(), ct.stride(0), tr_from
-    No = N // 2 if epi != EPI_PLAIN else N
-    if PROFILER is not None and d.tile == 0 and L.load().iir_gemm_resolve_tile(C.byref(d)) == 91:
+    No = N // 2 if epi not in (EPI_PLAIN, EPI_XATTN) else N
+    if xattn is not None:
+        cls = "gemm_kernel<64x128,gemm+xattn>"
+    elif PROFILER is not None and d.tile == 0 and L.load().iir_gemm_resolve_tile(C.byref(d)) == 91:
         cls = "gemm8_kernel<256x320,gemm>"             # the 8-wave kernel of csrc/gemm8.hip
     else:
         cls = "gemm_kernel<%s,%s>" % (_TILE_NAMES[tile % 10], "gemm" if wscale is None else "gemm-w8")
-    with _Timed(cls, 2.0 * M * N * K,
+    xa_flops = 4.0 * M * N * sum(k[4] for k in xattn[0]) if xattn is not None else 0.0
+    with _Timed(cls, 2.0 * M * N * K + xa_flops,
                 2.0 * (M * K + N * K * (1.0 if wscale is None else 0.5) + M * No + (M * No if res is not None else 0))):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out

@@ -718,3 +718,64 @@ def test_conv_groupnorm_from_partials(dev, R, H, Cin, Cout, stride, with_res, si
     want = (F.silu(want) if silu else want).permute(0, 2, 1).reshape(Mo, Cout)
     _close(fused, want, rtol=4e-3, atol=4e-3, what="GroupNorm from producer partials")
     assert (fused.float() - three.float()).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())
+
+
+# ---- round 3: to_q + text / IP cross-attention in one launch (IIR_EPI_XATTN) ------------------------------------------------------
+@pytest.mark.parametrize("R,T,heads,K,tk,ti,fold", [(2, 1024, 20, 1280, 77, 64, True), (2, 4096, 10, 640, 77, 64, True), (1, 128, 2, 128, 77, 64, False),
+                                                    (3, 64, 4, 192, 13, 4, False), (2, 256, 2, 256, 80, 1, True)])
+def test_gemm_cross_attention_epilogue(dev, R, T, heads, K, tk, ti, fold):
+    """`attn2.to_q` (LayerNorm folded or not) whose workgroups run the two SDPA calls + add of TA_IPAttnProcessor2_0
+    (module/ip_adapter/attention_processor.py:1140,1165,1185,1192) on the q tile they have just finished.  Against (a) the two
+    launches it replaces -- the same q projection, then `iir_attention_d64_f16` -- and (b) torch in fp32 on that q."""
+    from instantir_amd import ops
+    g = torch.Generator().manual_seed(R * T + heads + tk)
+    C, M = heads * 64, R * T
+    fac = ops.attn_q_factor()
+    a = _rand(g, M, K)
+    w, b = _rand(g, C, K, scale=K ** -0.5), _rand(g, C, scale=0.3)
+    kw = {}
+    if fold:                      # the residual stream and its LayerNorm partials, as the launch before `to_q` leaves them
+        w0 = _rand(g, K, K, scale=K ** -0.5)
+        res = (_rand(g, M, K).float() + 2.0 * torch.randn(M, 1, generator=g)).half()
+        gamma, beta = (1.0 + 0.2 * torch.randn(K, generator=g)).half(), (0.3 * torch.randn(K, generator=g)).half()
+        parts = ops.ln_parts(M, K, K)
+        if parts == 0:
+            pytest.skip("producer tile of this shape leaves no LayerNorm partials")
+        h = torch.empty(M, K, dtype=torch.half, device=dev)
+        stats = torch.zeros(parts, M, 2, dtype=torch.float32, device=dev)
+        ops.gemm(a.to(dev), w0.to(dev), h, res=res.to(dev), ln_out=stats)
+        f = ops.LnFold((w.float() * fac).to(dev), gamma.to(dev), beta.to(dev), bias=(b.float() * fac).to(dev), eps=1e-5)
+        a_dev, w_dev, b_dev = h, f.w, f.bias
+        kw["ln_in"] = (stats, f.colsum, f.eps)
+    else:
+        a_dev, w_dev, b_dev = a.to(dev), (w.float() * fac).half().to(dev), (b.float() * fac).half().to(dev)
+    segs, kvh = [], []
+    for L in (tk, ti):
+        k, v = _rand(g, R, L, C), _rand(g, R, L, C)
+        tp = (L + 7) // 8 * 8
+        vt = torch.zeros(C, R * tp, dtype=torch.half, device=dev)
+        for r in range(R):
+            vt[:, r * tp:r * tp + L] = v[r].T.to(dev)
+        segs.append((k.reshape(-1, C).to(dev), L, vt, tp, L))
+        kvh.append((k, v))
+    q = torch.empty(M, C, dtype=torch.half, device=dev)
+    ops.gemm(a_dev, w_dev, q, bias=b_dev, **kw)
+    two = torch.empty(M, C, dtype=torch.half, device=dev)
+    ops.attention(q, two, segs, R, heads, T, q_prescaled=True)
+    one = torch.full((M, C), float("nan"), dtype=torch.half, device=dev)
+    ops.gemm(a_dev, w_dev, one, bias=b_dev, epi=ops.EPI_XATTN, xattn=(segs, T), **kw)
+    torch.cuda.synchronize()
+    qf = q.float().cpu().reshape(R, T, heads, 64).transpose(1, 2) * math.log(2.0)          # q carries scale * log2(e)
+    want = 0
+    for k, v in kvh:
+        sp = lambda x: x.float().reshape(R, -1, heads, 64).transpose(1, 2)
+        want = want + torch.softmax(qf @ sp(k).transpose(-1, -2), dim=-1) @ sp(v)
+    want = want.transpose(1, 2).reshape(M, C)
+    assert torch.isfinite(one).all()
+    _close(one, want, rtol=3e-3, atol=3e-3, what="fused to_q + cross-attention vs torch")
+    _close(one, two.float().cpu(), rtol=3e-3, atol=3e-3, what="fused vs the two launches")
+    with pytest.raises(ValueError):
+        ops.gemm(a_dev, w_dev, one, bias=b_dev, epi=ops.EPI_XATTN, **kw)
+    from instantir_amd.lib import HipLibraryError
+    with pytest.raises(HipLibraryError):                # rows of an image must be whole 64-row tiles
+        ops.gemm(a_dev, w_dev, one, bias=b_dev, epi=ops.EPI_XATTN, xattn=(segs, T + 8), **kw)

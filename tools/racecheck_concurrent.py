@@ -134,6 +134,16 @@ for (M8, N8, K8, geglu8) in [(2048, 10240, 1280, True), (4096, 10240, 1280, True
         w8, b8 = pair_rows(w8[:N8 // 2], w8[N8 // 2:]), pair_rows(b8[:N8 // 2], b8[N8 // 2:])
     screen(f"gemm8 (256x320, 8 waves) {M8}x{N8}x{K8} {'GEGLU' if geglu8 else 'plain'}",
            lambda o: ops.gemm(x8, w8, o, bias=b8, tile=91, epi=ops.EPI_GEGLU if geglu8 else ops.EPI_PLAIN), [(M8, N8 // 2 if geglu8 else N8)])
+# to_q + cross-attention in one launch (IIR_EPI_XATTN), level-2 and level-1 geometry
+for (Rx, Tx, hx) in [(2, 1024, 20), (2, 4096, 10)]:
+    Cx = hx * 64
+    xa_a, xa_w = rnd(Rx * Tx, Cx), rnd(Cx, Cx, scale=Cx ** -0.5 * ops.attn_q_factor())
+    xa_segs = []
+    for Lx in (77, 64):
+        tpx = (Lx + 7) // 8 * 8
+        xa_segs.append((rnd(Rx * Lx, Cx), Lx, rnd(Cx, Rx * tpx), tpx, Lx))
+    screen(f"gemm + cross-attention epilogue R={Rx} T={Tx} heads={hx}",
+           lambda o: ops.gemm(xa_a, xa_w, o, epi=ops.EPI_XATTN, xattn=(xa_segs, Tx)), [(Rx * Tx, Cx)])
 tx = rnd(154, 1280)
 screen("transpose 154x1280 -> (1280, 160)", lambda o: ops.transpose(tx, o, 160), [(1280, 160)])
 # adaLN batch: 8 jobs of the step's geometry (2 rows x 64 IP tokens, C = 1280 / 640), half of them transposed
