@@ -56,3 +56,37 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     a.nseg = 3
     assert h.iir_attention_d64_f16(ctypes.byref(a), None) == -1
     assert h.iir_silu_f16(4096, 4096, 7, None) == -1              # n % 8
+
+
+def test_xattn_epilogue_arguments_are_validated_without_a_gpu():
+    """IIR_EPI_XATTN (to_q + cross-attention in one launch): every precondition the header states is refused with -1 before
+    any HIP call."""
+    h = lib.load()
+
+    def desc():
+        d = lib.GemmDesc()
+        d.A = d.W = d.C = 4096
+        d.lda = d.ldc = 256
+        d.M, d.N, d.K = 128, 256, 256
+        d.epi = lib.EPI_XATTN
+        kv = (lib.AttnKV * 2)()
+        for i, t in enumerate((77, 64)):
+            kv[i].K = kv[i].Vt = 4096
+            kv[i].ldk, kv[i].k_batch_stride, kv[i].ldvt, kv[i].vt_batch_stride, kv[i].Tkv = 256, 256 * t, 160, 80, t
+        d.xattn_kv, d.xattn_tq = kv, 64
+        return d, kv
+
+    d, kv = desc()
+    d.xattn_kv = None
+    assert h.iir_gemm_f16(ctypes.byref(d), None) == -1            # no K / V
+    for field, bad in (("xattn_tq", 72), ("xattn_tq", 0), ("N", 192), ("M", 96), ("act", lib.ACT_SILU), ("res", 4096), ("dtype", 1),
+                       ("tile", 5), ("c_f32", 1)):
+        d, kv = desc()
+        setattr(d, field, bad)
+        assert h.iir_gemm_f16(ctypes.byref(d), None) == -1, field
+    for seg, field, bad in ((0, "Tkv", 81), (1, "Tkv", 65), (0, "Tkv", 0), (1, "ldk", 100), (0, "vt_batch_stride", 77), (1, "K", 4100)):
+        d, kv = desc()
+        setattr(kv[seg], field, bad)
+        assert h.iir_gemm_f16(ctypes.byref(d), None) == -1, (seg, field)
+    d, kv = desc()
+    assert h.iir_gemm_resolve_tile(ctypes.byref(d)) == 93         # the valid descriptor resolves to the head-aligned 64 x 128 tile

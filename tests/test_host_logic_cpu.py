@@ -200,3 +200,24 @@ def test_oracle_lora_zero_b_is_noop_and_residuals_are_additive():
     zeros = [torch.zeros(R, c, h, h) for c, h in zip(W.skip_channels(cfg), hs)]
     y2 = nets.unet_forward(P, cfg, x, 10, ctx, pooled, tid, ip, zeros, torch.zeros(R, cfg.block_out_channels[-1], 2, 2))
     assert torch.equal(y0, y2)
+
+
+def test_copy_state_refreshes_in_place_and_reports_mismatches():
+    """`pipeline._copy_state`: a later call's hoisted state is copied INTO the tensors the step graphs were captured on; the
+    device pointer table (`ada_jobs`) is left alone; any difference in structure, shape or dtype is reported, not papered over."""
+    from instantir_amd.pipeline import _copy_state
+    mk = lambda v: {"R": 2, "H": 4, "aug_emb": torch.full((2, 3), v), "ada_jobs": torch.tensor([int(v)]),
+                    "kv": {"b0": {"tk": torch.full((4, 2), v, dtype=torch.float16), "tpad": 8}}}
+    dst, src = mk(1.0), mk(5.0)
+    keep = (dst["aug_emb"], dst["kv"]["b0"]["tk"])
+    assert _copy_state(dst, src)
+    assert dst["aug_emb"] is keep[0] and dst["kv"]["b0"]["tk"] is keep[1]                 # same storage ...
+    assert float(keep[0][0, 0]) == 5.0 and float(keep[1][0, 0]) == 5.0                    # ... new values
+    assert int(dst["ada_jobs"][0]) == 1                                                   # pointer table untouched
+    assert _copy_state(None, None) and not _copy_state(dst, None) and not _copy_state(None, src)
+    for mutate in (lambda s: s.update(R=3), lambda s: s["kv"]["b0"].update(tpad=16), lambda s: s["kv"].update(b1={}),
+                   lambda s: s.update(aug_emb=torch.zeros(2, 4)), lambda s: s["kv"]["b0"].update(tk=torch.zeros(4, 2)),
+                   lambda s: s.pop("H")):
+        other = mk(2.0)
+        mutate(other)
+        assert not _copy_state(mk(1.0), other)
