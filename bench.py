@@ -316,13 +316,14 @@ def main():
         traffic = None
         if not args.tiny and args.size == 1024:
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            pm = sorted(p_ for p_ in os.listdir(pdir) if p_.endswith("_pmc_traffic.json")) if os.path.isdir(pdir) else []
+            latest = lambda n: (n.split("_")[0], "final" in n, n)          # newest round, its final pass before its mid-round one
+            pm = sorted((p_ for p_ in os.listdir(pdir) if p_.endswith("_pmc_traffic.json")), key=latest) if os.path.isdir(pdir) else []
             if pm:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pm[-1])) as f:
                     traffic = json.load(f)["classes"].get(name, {}).get("hbm_bytes_per_launch")
         mfma_busy = None
         if not args.tiny and args.size == 1024:
-            pb = sorted(p_ for p_ in os.listdir(pdir) if p_.endswith("_pmc_mfma_busy.json")) if os.path.isdir(pdir) else []
+            pb = sorted((p_ for p_ in os.listdir(pdir) if p_.endswith("_pmc_mfma_busy.json")), key=latest) if os.path.isdir(pdir) else []
             if pb:
                 with open(os.path.join(pdir, pb[-1])) as f:
                     mfma_busy = json.load(f)["classes"].get(name, {}).get("mfma_busy_frac")

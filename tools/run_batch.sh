@@ -1,8 +1,11 @@
 #!/bin/bash
+set -e
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r3
-for v in "0 --no-graph" "1 --no-graph" "0 " "0 --no-graph" "1 --no-graph"; do
-set -- $v
-IIR_CU_SPLIT=$1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-roofline --no-vae --no-e2e --steps 20 $2 2>/tmp/err.log | tail -1 > /tmp/b.json
-python -c "import json; d=json.load(open('/tmp/b.json')); print('cu_split $1 $2', d['ms_per_step'], d['config']['finite'])" || tail -5 /tmp/err.log
-done
+bash tools/final_profiles.sh
+python bench.py --config 4 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final/bench_config4_fp8.json
+python bench.py --config 4 --fp16 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final/bench_config4_fp16.json
+python -c "
+import json
+for n in ('fp8','fp16'):
+    d=json.load(open('gpurun_out/final/bench_config4_%s.json'%n)); print('config4', n, d['ms_per_step'], d['value'], d['unit'])"
