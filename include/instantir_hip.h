@@ -92,6 +92,10 @@ typedef struct iir_gemm_desc {
     /* 1 <= Tkv[1] <= 64, ldk / ldvt / batch strides % 8 == 0, no res / rowbias / act / Ct / c_f32 / wscale / *_stats_out / split-K.      */
     const iir_attn_kv* xattn_kv;   /* [2]: text K / V^T, IP-token K / V^T (layouts as for iir_attention_d64_f16)                       */
     int32_t xattn_tq;              /* query rows per image (row m belongs to image m / xattn_tq)                                      */
+    /* BASELINE configs[4], both operands in fp8: with `wscale` set and a_fp8 != 0, A holds fp8-E4M3 (OCP) BYTES [M][K] too (lda in    */
+    /* bytes, % 16; K % 128 == 0): C = epi((A8 . W8^T) * wscale[n] * a_scale ...).  Half the 128-byte lines per FLOP of the fp16 form. */
+    int32_t a_fp8;
+    float a_scale;                 /* 0 means 1                                                                                       */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections

@@ -89,8 +89,15 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // 7 pieces per K tile, with its SIMD's matrix pipe idle behind it (MI355X_MICROARCH.md, LDS-DMA issue cost) -- the "serial
 // round trip" of DESIGN.md section 5.6.  Both kinds of wave meet at the one barrier per K tile; the protocol (tile kt+1 landed
 // and tile kt's buffer drained at the barrier of iteration kt) is unchanged.  All 2*NW waves share the epilogue write-out.
-template <typename E, int BM, int BN, int ST, bool CONV, int WAVES_M = 2, bool W8 = false, bool LW = false>
+// F8 (round 3): BOTH operands are fp8-E4M3 bytes.  A row of 128 K values is the same 128 bytes as a row of 64 halves, so the host
+// hands the launch over with K and lda counted in 2-byte units and everything up to the fragment registers -- addresses, LDS-DMA
+// staging, swizzle, conflict-free 16-byte fragment reads -- is the fp16 path unchanged; the 16 bytes a lane holds are 16 K values,
+// fed to two `v_mfma_f32_16x16x32_fp8_fp8` (low and high 8 bytes: any split of the contraction index is valid as long as both
+// operands use the same one).  Per K tile: the same MFMA count per K value as fp16, HALF the 128-byte lines per FLOP -- which is
+// what the one-per-CU GEMMs are bound by.  Scales: wscale[n] per output channel, a_scale for the activations.
+template <typename E, int BM, int BN, int ST, bool CONV, int WAVES_M = 2, bool W8 = false, bool LW = false, bool F8 = false>
 __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1)) void gemm_kernel(const Geo g) {
+    static_assert(!(F8 && (W8 || CONV)), "the all-fp8 build covers the linear layers; W8 is the fp16-activation form");
     static_assert(!(W8 && CONV), "the fp8-weight build covers the linear layers only");
     static_assert(!(LW && W8), "loader waves: fp16 / bf16 operands only");
     using E4 = typename ET<E>::x4;
@@ -345,7 +352,19 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         for (int i = 0; i < MI; ++i) for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(af[i]), "v"(bf[j]));
         return;
 #endif
-        if constexpr (!W8) {
+        if constexpr (F8) {
+            typedef long l2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const l2 a2 = __builtin_bit_cast(l2, af[i]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const l2 b2 = __builtin_bit_cast(l2, bf[j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[0], a2[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[1], a2[1], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else if constexpr (!W8) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -689,13 +708,13 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
             const int n = n0 + lc;
             if (n >= g.N) continue;
             float sc[4] = {1.f, 1.f, 1.f, 1.f}, c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
-            if (W8) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) sc[t] = ws[t]; }
+            if (W8 || F8) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) sc[t] = ws[t] * g.a_scale; }
             for (int t = 0; t < 4; ++t) { c1[t] = pre_c1[j][t]; c0[t] = (float)pre_c0[j][t]; }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int lr = lrs[i];
                 float v[4];
-                for (int t = 0; t < 4; ++t) v[t] = W8 ? acc[i][j][t] * sc[t] : acc[i][j][t];
+                for (int t = 0; t < 4; ++t) v[t] = (W8 || F8) ? acc[i][j][t] * sc[t] : acc[i][j][t];
                 for (int t = 0; t < 4; ++t) v[t] = fmaf(v[t], rss[i].x, fmaf(rss[i].y, c1[t], c0[t]));     // (1, 0) without ln_in
                 if (g.rowbias) { E4 b = *(const E4*)(g.rowbias + (long)(ms[i] / g.rows_per_rb) * g.ldrb + n); for (int t = 0; t < 4; ++t) v[t] += (float)b[t]; }
                 if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
@@ -715,13 +734,13 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
             const int n = n0 + wn * WN + j * 16 + fq * 4;           // permuted column held by this lane
             const bool in_n = n < g.N;
             float sc[4] = {1.f, 1.f, 1.f, 1.f}, c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
-            if (W8 && in_n) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) sc[t] = ws[t]; }
+            if ((W8 || F8) && in_n) { const f32x4 ws = *(const f32x4*)(g.wscale + n); for (int t = 0; t < 4; ++t) sc[t] = ws[t] * g.a_scale; }
             for (int t = 0; t < 4; ++t) { c1[t] = pre_c1[j][t]; c0[t] = (float)pre_c0[j][t]; }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int lr = lrs[i];
                 float a[4];
-                for (int t = 0; t < 4; ++t) a[t] = W8 ? acc[i][j][t] * sc[t] : acc[i][j][t];
+                for (int t = 0; t < 4; ++t) a[t] = (W8 || F8) ? acc[i][j][t] * sc[t] : acc[i][j][t];
                 for (int t = 0; t < 4; ++t) a[t] = fmaf(a[t], rss[i].x, fmaf(rss[i].y, c1[t], c0[t]));
                 float b[4];
                 for (int t = 0; t < 4; ++t) b[t] = __shfl_xor(a[t], 32, 64);     // all lanes take part in the exchange
@@ -963,7 +982,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA touches must land before the LDS is released
 }
 
-template <typename E, int BM, int BN, int ST, int WAVES_M = 2, bool W8 = false, bool LW = false>
+template <typename E, int BM, int BN, int ST, int WAVES_M = 2, bool W8 = false, bool LW = false, bool F8 = false>
 int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     Geo g = g0;
     g.tiles_m = (g.M + BM - 1) / BM;
@@ -1013,7 +1032,12 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
         done[dev] |= 1ull << slot;
         return true;
     };
-    if constexpr (W8) {
+    if constexpr (F8) {
+        if (conv || g.splitk == 2) return IIR_EINVAL;
+        if (!ensure_lds((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, LW, true>)) return IIR_ELAUNCH;
+        iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, false, LW, true>, grid, block, lds, stream, g);
+        return iir_launch_status();
+    } else if constexpr (W8) {
         if (!ensure_lds((const void*)gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>)) return IIR_ELAUNCH;
         iir_launch(gemm_kernel<E, BM, BN, ST, false, WAVES_M, true>, grid, block, lds, stream, g);
         return iir_launch_status();
@@ -1041,6 +1065,12 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
 // fp16 build of every tile / ring depth; bf16 build (the VAE) of the two-stage tiles the chooser picks for it
 template <int BM, int BN, int ST, int WAVES_M = 2>
 int launch(const Geo& g, bool conv, hipStream_t stream) {
+    if (g.f8) {               // all-fp8 build: the 4-wave tiles the chooser picks for the transformer linears
+        if constexpr (WAVES_M == 2 && (ST == 2 || (ST == 3 && BM == 64 && BN == 160))) {
+            if (conv || g.dtype != IIR_DT_F16) return IIR_EINVAL;
+            return launch_t<f16, BM, BN, ST, WAVES_M, false, false, true>(g, false, stream);
+        } else return IIR_EINVAL;
+    }
     if (g.wscale) {           // fp8-weight build: fp16 activations, linear layers, the 4-wave tiles
         if constexpr (WAVES_M == 2 && (ST == 2 || (ST == 3 && BM == 64 && BN == 160))) {
             if (conv || g.dtype != IIR_DT_F16 || g.splitk == 2) return IIR_EINVAL;
@@ -1056,6 +1086,10 @@ int launch(const Geo& g, bool conv, hipStream_t stream) {
 
 template <int BM, int BN, int ST>
 int lw_launch(const Geo& g, bool conv, hipStream_t stream) {
+    if (g.f8) {
+        if constexpr (ST == 3 && BM == 64 && BN == 160) { if (conv) return IIR_EINVAL; return launch_t<f16, BM, BN, ST, 2, false, true, true>(g, false, stream); }
+        else return IIR_EINVAL;
+    }
     if (g.wscale || g.dtype != IIR_DT_F16 || g.splitk == 2) return IIR_EINVAL;
     if constexpr (ST == 3) return launch_t<f16, BM, BN, ST, 2, false, true>(g, conv, stream);
     else { if (conv) return IIR_EINVAL; return launch_t<f16, BM, BN, ST, 2, false, true>(g, false, stream); }
@@ -1126,12 +1160,12 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
     // gemm8.hip (142 FLOP per staged byte against 71 for two 128x160 workgroups per CU).  IIR_G8=0 switches it off (A/B).
     if (tile == 0 && gemm8_auto(g, conv)) return iir::gemm8_launch(g, 320, stream);
     if (tile == 91 || tile == 92) return conv ? IIR_EINVAL : iir::gemm8_launch(g, tile == 91 ? 320 : 256, stream);
-    if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
+    if (tile == 0) tile = pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.f8 ? 2 * g.K : g.K);
     if (tile < 10) {
         // ring depth: with at most one workgroup per CU nothing else hides the tile latency, and a long K loop
         // amortises the deeper prologue -> 3 stages for the 64x160 tile (measured +17..40 % on K >= 2560, M*N = 2048x1280)
         const long blocks = (long)((g.M + kTiles[tile].bm - 1) / kTiles[tile].bm) * ((g.N + kTiles[tile].bn - 1) / kTiles[tile].bn);
-        const bool one_per_cu = tile == 5 && blocks <= 256 && g.K >= one_per_cu_min_k() && g.dtype == IIR_DT_F16;
+        const bool one_per_cu = tile == 5 && blocks <= 256 && (g.f8 ? 2 * g.K : g.K) >= one_per_cu_min_k() && g.dtype == IIR_DT_F16;     // (all-fp8: g.K counts 2-byte units)
         const int stages = one_per_cu ? one_per_cu_stages() : IIR_DEFAULT_STAGES;
         // one workgroup per CU and a plain GEMM: the loader-wave build (kbench, warm: 2048x1280x1280 456 -> 535 TFLOP/s,
         // K = 5120 645 -> 707; the per-tile slope stays at the ~70 GB/s per-CU L2 -> LDS fill rate, the fixed part drops)
@@ -1140,7 +1174,7 @@ int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {
         static const bool lw2 = getenv("IIR_T5_LW2") && atoi(getenv("IIR_T5_LW2")) == 1;     // experiment: 2-stage loader-wave build (58 KB of LDS: two kernels can share a CU)
         if (one_per_cu && lw2 && !conv && !g.wscale && g.splitk != 2) tile = 75;
         else
-        if (one_per_cu && lw_on && (!conv || (lw_conv && stages == 3)) && !g.wscale && g.splitk != 2 && stages >= 3 && stages <= 5) tile = stages == 3 ? 55 : stages == 4 ? 65 : 85;
+        if (one_per_cu && lw_on && (!conv || (lw_conv && stages == 3)) && (!g.wscale || (g.f8 && stages == 3)) && g.splitk != 2 && stages >= 3 && stages <= 5) tile = stages == 3 ? 55 : stages == 4 ? 65 : 85;
         else
         tile += 10 * stages;
     }
@@ -1240,7 +1274,7 @@ extern "C" int iir_gemm_resolve_tile(const iir_gemm_desc* d) {
     if (g.xa_on) return 93;
     if (d->tile != 0) return d->tile;
     if (gemm8_auto(g, false)) return 91;
-    return pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.K);
+    return pick_tile(g.M, g.N, g.epi != IIR_EPI_PLAIN, g.f8 ? 2 * g.K : g.K);
 }
 
 static int fill_gemm_geo(const iir_gemm_desc* d, Geo& g) {
@@ -1283,6 +1317,13 @@ static int fill_gemm_geo(const iir_gemm_desc* d, Geo& g) {
         if (d->c_f32 || d->K % 64 || (uintptr_t)d->W % 16 || (uintptr_t)d->wscale % 16 || d->dtype != IIR_DT_F16) return IIR_EINVAL;
         g.wscale = (const float*)d->wscale;
         g.sk_slabs = nullptr;
+    }
+    g.a_scale = 1.f;
+    if (d->a_fp8) {           // A is fp8-E4M3 [M][K] bytes as well (lda in bytes): both operands by 128-byte rows of 128 K values
+        if (!d->wscale || d->K % 128 || d->lda % 16 || (uintptr_t)d->A % 16 || d->ln_stats_in || d->Ct || d->epi == IIR_EPI_XATTN || d->splitk_ws) return IIR_EINVAL;
+        g.f8 = 1;
+        g.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
+        g.K = d->K / 2; g.lda = d->lda / 2;          // counted in 2-byte units from here on: the fp16 staging path unchanged
     }
     if (d->Ct) {
         if (d->epi != IIR_EPI_PLAIN || d->tr_from < 0 || d->tr_from >= d->N || d->tr_from % 8 || d->ldct < d->M) return IIR_EINVAL;

@@ -47,6 +47,7 @@ class GemmDesc(C.Structure):
         ("ln_eps", C.c_float), ("ln_colsum", C.c_void_p),
         ("gn_stats_out", C.c_void_p),
         ("xattn_kv", C.POINTER(AttnKV)), ("xattn_tq", C.c_int32),
+        ("a_fp8", C.c_int32), ("a_scale", C.c_float),
     ]
 
 

@@ -133,6 +133,52 @@ def quantize_fp8_rows(w):
     return q, scale
 
 
+def gemm_fp8(a8, w8, out, a_scale=1.0, bias=None, res=None, epi=EPI_PLAIN, act=ACT_NONE, tile=0, prefetch=None):
+    """out = epi((a8 @ w8.q.T) * w8.scale[None, :] * a_scale ...): BOTH operands fp8-E4M3 (`iir_gemm_desc.a_fp8`).
+    a8 (M, K) torch.float8_e4m3fn (or its bytes) view with a 16-byte-aligned row stride, K % 128 == 0; w8 an `Fp8Weight`;
+    out / bias / res fp16.  One K tile is 128 K values = the same 128-byte rows the fp16 path stages for 64."""
+    if not isinstance(w8, Fp8Weight):
+        raise ValueError("gemm_fp8: w8 must be an Fp8Weight")
+    if a8.dtype not in (torch.float8_e4m3fn, torch.uint8) or a8.dim() != 2 or a8.stride(1) != 1 or not a8.is_cuda:
+        raise ValueError("gemm_fp8: a8 must be a 2-D CUDA view of torch.float8_e4m3fn (or its bytes) with contiguous rows")
+    M, K = a8.shape
+    N = w8.q.shape[0]
+    if w8.q.shape[1] != K or K % 128 or a8.stride(0) % 16:
+        raise ValueError("gemm_fp8: K must match, K % 128 == 0, row stride % 16 == 0")
+    dt = torch.float16
+    _chk2d(out, "out", dt)
+    n_out = N if epi == EPI_PLAIN else N // 2
+    if out.shape != (M, n_out):
+        raise ValueError(f"out shape {tuple(out.shape)} != {(M, n_out)}")
+    for t_, n_ in ((bias, "bias"), (res, "res")):
+        if t_ is not None and t_.dtype != dt:
+            raise ValueError(f"{n_}: fp16 expected")
+    d = L.GemmDesc()
+    d.A, d.lda = a8.data_ptr(), a8.stride(0)
+    d.W, d.wscale = w8.q.data_ptr(), w8.scale.data_ptr()
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.bias = _p(bias)
+    if res is not None:
+        _chk2d(res, "res", dt)
+        d.res, d.ldr = res.data_ptr(), res.stride(0)
+    d.epi, d.act, d.out_scale, d.tile = epi, act, 1.0, tile
+    d.dtype, d.a_fp8, d.a_scale = _DT[dt], 1, float(a_scale)
+    if prefetch is not None:
+        d.prefetch, d.prefetch_bytes = prefetch
+    t_name = tile if tile else auto_tile(M, N, epi != EPI_PLAIN, K)
+    with _Timed("gemm_kernel<%s,gemm-f8>" % _TILE_NAMES[t_name % 10], 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * n_out * (2 if res is not None else 1)):
+        L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
+    return out
+
+
+def quantize_fp8_tensor(x):
+    """Per-tensor E4M3 quantisation of an activation matrix: (bytes as torch.float8_e4m3fn, scale) with x ~= bytes * scale."""
+    x32 = x.float()
+    scale = float(x32.abs().amax().clamp_min(1e-12) / FP8_MAX)
+    return (x32 / scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).contiguous(), scale
+
+
 class LnFold:
     """A LayerNorm folded into the nn.Linear that follows it (weight-pack time): `w` = W . diag(gamma) (fp16, or an Fp8Weight of
     it), `colsum[n]` = sum_k w[n][k] in fp32 (of the STORED values, so the mean term cancels exactly), `bias` = b + W . beta."""

@@ -779,3 +779,37 @@ def test_gemm_cross_attention_epilogue(dev, R, T, heads, K, tk, ti, fold):
     from instantir_amd.lib import HipLibraryError
     with pytest.raises(HipLibraryError):                # rows of an image must be whole 64-row tiles
         ops.gemm(a_dev, w_dev, one, bias=b_dev, epi=ops.EPI_XATTN, xattn=(segs, T + 8), **kw)
+
+
+# ---- round 3: both operands in fp8 (iir_gemm_desc.a_fp8) ---------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,mode,tile", [(256, 320, 256, "plain", 0), (2048, 1280, 1280, "res", 0), (2048, 1280, 5120, "plain", 0),
+                                             (8192, 640, 640, "res", 0), (512, 2560, 640, "geglu", 0), (300, 160, 384, "plain", 25),
+                                             (4096, 1280, 1280, "plain", 21), (2048, 1280, 1280, "plain", 55)])
+def test_gemm_fp8_both_operands(dev, M, N, K, mode, tile):
+    """A and W as E4M3 bytes, 128 K values per K tile (two fp8 MFMAs on the 16 bytes a lane reads).  Exact reference: the same
+    bytes dequantised, multiplied in fp64 -- products of fp8 values are exact in fp32, only the accumulation order differs."""
+    from instantir_amd import ops
+    from instantir_amd.packing import pair_rows
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
+    a8, sa = ops.quantize_fp8_tensor(a.to(dev))
+    if mode == "geglu":
+        w, b = pair_rows(w[:N // 2], w[N // 2:]), pair_rows(b[:N // 2], b[N // 2:])
+    q, sc = ops.quantize_fp8_rows(w.to(dev))
+    w8 = ops.Fp8Weight(q, sc)
+    res = _rand(g, M, N) if mode == "res" else None
+    y = (a8.float().double().cpu() * sa) @ (q.float().double().cpu() * sc.double().cpu()[:, None]).T + b.double()
+    if mode == "geglu":
+        # un-permute: rows [16 blk, 16 blk + 8) are value rows, the next 8 their gates
+        yb = y.reshape(M, N // 16, 16)
+        want = (yb[:, :, :8] * F.gelu(yb[:, :, 8:])).reshape(M, N // 2)
+        out = torch.empty(M, N // 2, dtype=torch.half, device=dev)
+        ops.gemm_fp8(a8, w8, out, a_scale=sa, bias=b.to(dev), epi=ops.EPI_GEGLU, tile=tile)
+    else:
+        want = y + (res.double() if res is not None else 0)
+        out = torch.empty(M, N, dtype=torch.half, device=dev)
+        ops.gemm_fp8(a8, w8, out, a_scale=sa, bias=b.to(dev), res=res.to(dev) if res is not None else None, tile=tile)
+    torch.cuda.synchronize()
+    _close(out, want.float(), rtol=2e-3, atol=2e-3, what="fp8 x fp8 gemm")
+    with pytest.raises(ValueError):
+        ops.gemm_fp8(a8[:, :K - 64], ops.Fp8Weight(q[:, :K - 64].contiguous(), sc), out)       # K % 128

@@ -36,6 +36,16 @@ def gemm_bench():
             for tile in TILES:
                 t = timeit(lambda: ops.gemm(a, w8, outg, tile=tile, epi=ops.EPI_GEGLU) if geglu else ops.gemm(a, w8, out, tile=tile))
                 row += f"  t{tile} {2*M*N*K/t/1e12:6.0f}"
+        if os.environ.get("F8", "0") == "1" and K % 128 == 0:       # both operands fp8 (128 K values per K tile)
+            w8 = ops.Fp8Weight(*ops.quantize_fp8_rows(w))
+            a8, sa = ops.quantize_fp8_tensor(a)
+            row += "  | fp8 x fp8:"
+            for tile in TILES:
+                try:
+                    t = timeit(lambda: ops.gemm_fp8(a8, w8, outg, a_scale=sa, tile=tile, epi=ops.EPI_GEGLU) if geglu else ops.gemm_fp8(a8, w8, out, a_scale=sa, tile=tile))
+                    row += f"  t{tile} {2*M*N*K/t/1e12:6.0f}"
+                except Exception:
+                    row += f"  t{tile}    n/a"
         t = timeit(lambda: torch.matmul(a, w.T, out=out))
         row += f"  | hipblaslt {2*M*N*K/t/1e12:7.1f} TF"
         print(row, flush=True)
