@@ -96,6 +96,8 @@ typedef struct iir_gemm_desc {
     /* bytes, % 16; K % 128 == 0): C = epi((A8 . W8^T) * wscale[n] * a_scale ...).  Half the 128-byte lines per FLOP of the fp16 form. */
     int32_t a_fp8;
     float a_scale;                 /* 0 means 1                                                                                       */
+    int32_t c_fp8;                 /* != 0: C is a BYTE matrix of fp8-E4M3 (ldc in bytes, % 8; whole tiles; PLAIN / GEGLU epilogues, */
+                                   /*   no *_stats_out / Ct / c_f32): the value is rounded to fp16 first, then to fp8 (scale 1)     */
 } iir_gemm_desc;
 
 /* Replaces nn.Linear / F.linear call sites: attention projections
@@ -112,6 +114,8 @@ int iir_gemm_pick_tile(int32_t M, int32_t N, int32_t K, int32_t paired);
 int iir_gemm_resolve_tile(const iir_gemm_desc* d);
 /* 1 when the tile = 0, plain-epilogue fp16 launch of (M, N, K) can leave GroupNorm partials in `gn_stats_out` */
 int iir_gemm_gn_supported(int32_t M, int32_t N, int32_t K, int32_t is_conv);
+/* 1 when the tile = 0 all-fp8 launch (a_fp8) of (M, N, K) can store its result as fp8 bytes (c_fp8): whole tiles */
+int iir_gemm_fp8_out_supported(int32_t M, int32_t N, int32_t K, int32_t paired);
 /* bytes of split-K workspace an (M, N) problem can use (0: the split form does not apply to it) */
 int64_t iir_gemm_splitk_workspace_bytes(int32_t M, int32_t N);
 /* 1 if a tile = 0 launch of this problem with a workspace of ws_bytes takes the two-slice split-K form (128x160 tile) */
@@ -159,6 +163,8 @@ typedef struct iir_attn_desc {
     int32_t causal;                                 /* != 0: key j is visible to query i only if j <= i */
     int32_t q_prescaled;                            /* != 0: Q already holds q * scale * log2(e) (the caller folded the factor
                                                      *   into the projection weights); the kernel then uses Q as it stands   */
+    int32_t o_fp8;                                  /* != 0: O is a BYTE matrix of fp8-E4M3 (ldo, o_batch_stride in bytes): the
+                                                     *   A operand of an all-fp8 `to_out` GEMM (iir_gemm_desc.a_fp8)         */
 } iir_attn_desc;
 
 /* Replaces F.scaled_dot_product_attention at module/ip_adapter/attention_processor.py:394 (nseg=1)
@@ -185,7 +191,8 @@ int64_t iir_groupnorm_workspace_bytes(int32_t R, int32_t groups);
 
 /* nn.LayerNorm (module/min_sdxl.py:534-538; resampler.py:15,43-44,98) and AdaLayerNorm's
  * LN(x)*(1+scale)+shift (attention_processor.py:24-25).  gamma/beta/shift/scale may be NULL.
- * transposed != 0 stores y^T (used to emit the IP-adapter V^T image directly):
+ * transposed == 2 stores y as fp8-E4M3 BYTES (Y a byte matrix, ldy in bytes: the A operand of an all-fp8 GEMM, iir_gemm_desc.a_fp8);
+ * transposed == 1 stores y^T (used to emit the IP-adapter V^T image directly):
  *   Y[c][ (row / tr_rows) * tr_bstride + row % tr_rows ], row stride ldy. */
 int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ldy, int32_t rows, int32_t C, const void* gamma,
                       const void* beta, float eps, const void* shift, const void* scale, int64_t ldmod,

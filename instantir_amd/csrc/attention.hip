@@ -25,7 +25,7 @@ namespace {
 struct Seg { const f16* K; long ldk, kbs; const f16* Vt; long ldvt, vbs; int Tkv; };
 struct AGeo {
     const f16* Q; long ldq, qbs;
-    f16* O; long ldo, obs;
+    f16* O; long ldo, obs; int o_fp8;      // o_fp8: O is a byte matrix of fp8-E4M3 (ldo / obs in bytes)
     int Tq, nseg;
     int qtiles, npairs;   // query tiles per (batch, head); number of (batch, head) pairs; heads below
     int heads;
@@ -620,6 +620,7 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
             // ---- store: lane (q, hh) holds d = 32*db + 8*gq + 4*hh + [0,4) in regs 4*gq..4*gq+3
             if (qq < g.Tq) {
                 f16* op = g.O + (long)b * g.obs + (long)qq * g.ldo + h * 64;
+                char* op8 = (char*)g.O + (long)b * g.obs + (long)qq * g.ldo + h * 64;
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -627,7 +628,8 @@ __global__ __launch_bounds__(256, WPS) void attn_kernel2(const AGeo g) {
                         f16x4 v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = (f16)o[db][4 * gq + j];
-                        *(f16x4*)(op + db * 32 + gq * 8 + hh * 4) = v;
+                        if (g.o_fp8) *(int*)(op8 + db * 32 + gq * 8 + hh * 4) = iir_fp8x4(v);      // rounded to fp16 first, as the fp16 output would be
+                        else *(f16x4*)(op + db * 32 + gq * 8 + hh * 4) = v;
                     }
             }
         }
@@ -643,7 +645,7 @@ extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
     if (a->ldq % 8 || a->ldo % 4) return IIR_EINVAL;
     AGeo g{};
     g.Q = (const f16*)a->Q; g.ldq = a->ldq; g.qbs = a->q_batch_stride;
-    g.O = (f16*)a->O; g.ldo = a->ldo; g.obs = a->o_batch_stride;
+    g.O = (f16*)a->O; g.ldo = a->ldo; g.obs = a->o_batch_stride; g.o_fp8 = a->o_fp8 != 0;
     g.Tq = a->Tq; g.nseg = a->nseg;
     g.c = a->scale * 1.4426950408889634f;
     g.qpre = a->q_prescaled;
@@ -661,6 +663,7 @@ extern "C" int iir_attention_d64_f16(const iir_attn_desc* a, void* stream) {
     // waves per SIMD (no spills); default 0 = second generation, the 2-wave build when the grid cannot put more than two
     // workgroups on a CU anyway (measured: T = 1024 x 40 pairs 24.8 vs 27.2 us; T = 8192 462 vs 453 us).
     static const int version = getenv("IIR_ATTN_V") ? atoi(getenv("IIR_ATTN_V")) : 0;
+    if (g.o_fp8 && version == 1) return IIR_EINVAL;          // the first-generation kernel has no fp8 store
     // (ring depths 3 and 4 were built and measured: no change on any of the step's shapes, `profiles/r02_attn_ring_depth.log`;
     //  only the two-buffer instantiations are compiled)
     auto launch2 = [&](auto kern, int nb) {

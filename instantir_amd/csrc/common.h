@@ -27,6 +27,26 @@ template <> struct ET<bf16> {
 #define IIR_DT_F16 0
 #define IIR_DT_BF16 1
 
+// 8 halves -> 8 fp8-E4M3 (OCP) bytes: round to nearest even, saturating, element order kept (v_cvt_scalef32_pk_fp8_f16, scale 1).
+// The SAME conversion the fp8-weight GEMM applies to its fp16 activation fragments, so a producer that stores fp8 with this
+// helper hands the all-fp8 GEMM exactly the operand bytes the fp16-activation form would have formed in registers.
+__device__ __forceinline__ long iir_fp8x8(f16x8 v) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2 lo = {0, 0}, hi = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, (f16x2){v[0], v[1]}, 1.0f, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, (f16x2){v[2], v[3]}, 1.0f, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, (f16x2){v[4], v[5]}, 1.0f, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, (f16x2){v[6], v[7]}, 1.0f, true);
+    return (long)(unsigned)__builtin_bit_cast(int, lo) | ((long)__builtin_bit_cast(int, hi) << 32);
+}
+__device__ __forceinline__ int iir_fp8x4(f16x4 v) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2 lo = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, (f16x2){v[0], v[1]}, 1.0f, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, (f16x2){v[2], v[3]}, 1.0f, true);
+    return __builtin_bit_cast(int, lo);
+}
+
 #define IIR_OK 0
 #define IIR_EINVAL (-1)
 #define IIR_ELAUNCH (-2)

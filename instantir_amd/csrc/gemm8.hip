@@ -324,7 +324,7 @@ namespace iir {
 
 bool gemm8_covers(const Geo& g, int bn) {
     if (bn != 320 && bn != 256) return false;
-    if (g.dtype != IIR_DT_F16 || g.c_f32 || g.ln_out || g.gn_out || g.splitk == 2 || g.wscale || g.rowbias) return false;
+    if (g.dtype != IIR_DT_F16 || g.c_f32 || g.ln_out || g.gn_out || g.splitk == 2 || g.wscale || g.rowbias || g.c_fp8 || g.f8 || g.xa_on) return false;
     if (g.Ct && (g.epi != IIR_EPI_PLAIN || g.res || g.tr_from % bn || !g.ct_vec)) return false;      // transposed column range: whole tiles only
     if (g.epi != IIR_EPI_PLAIN && g.epi != IIR_EPI_GEGLU) return false;
     if (g.M % 256 || g.N % bn || g.K % 64 || g.K < 128) return false;

@@ -917,6 +917,9 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
             for (int k = 0; k < CH; ++k) {
                 const int c = tid + k * NT, r = c / CPR, cc = c - r * CPR;
                 if (TOTAL % NT != 0 && c >= TOTAL) break;
+                if constexpr (std::is_same<E, f16>::value) {
+                    if (g.c_fp8) { *(long*)((char*)g.C + (long)(m0 + r) * g.ldc + no_tile + cc * 8) = iir_fp8x8(o[k]); continue; }
+                }
                 iir::store16(g.C, ((long)(m0 + r) * g.ldc + no_tile + cc * 8) * 2, o[k], g.st_wt != 0);
             }
             if constexpr (LN_OUT_FITS) {
@@ -989,6 +992,11 @@ int launch_t(const Geo& g0, bool conv, hipStream_t stream) {
     g.tiles_n = (g.N + BN - 1) / BN;
     static const size_t dbg_pad = getenv("IIR_DBG_LDS_PAD") ? (size_t)atoi(getenv("IIR_DBG_LDS_PAD")) : 0;     // (5.8 bisection: force one workgroup per CU)
     const size_t lds = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)) + 256 * WAVES_M * 2 * (LW ? 2 : 1) + BM * 8 + dbg_pad;   // ring (reused as the output tile) + prefetch scratch (256 B per wave) + LayerNorm row statistics
+    if (g.c_fp8) {          // fp8 output: stored by the straight-line write-out only (whole tiles, 8-byte addressable rows)
+        if (conv || g.M % BM || g.N % BN || g.ldc % 8 || (uintptr_t)g.C % 8 || g.Ct || g.c_f32 || g.ln_out || g.gn_out || g.res_img_rows || g.y_img_rows ||
+            (g.res && !g.r_vec) || g.dtype != IIR_DT_F16) return IIR_EINVAL;
+        g.c_vec = 1; g.st_wt = 0;
+    }
     if (g.gn_out) {         // producer of GroupNorm partials: whole tiles, 16-byte rows, plain epilogue, rows of an image tile-aligned (caller)
         constexpr int RINGB = ST * (BM * 128 + (W8 ? BN * 64 : BN * 128)), NTH = 128 * WAVES_M * (LW ? 2 : 1);
         constexpr bool fits = BM % 64 == 0 && BN <= NTH && (BM * (2 * BN + 32) + 15) / 16 * 16 + (NTH / (BN / 8)) * BN * 8 <= RINGB;
@@ -1258,6 +1266,14 @@ extern "C" int iir_gemm_gn_supported(int32_t M, int32_t N, int32_t K, int32_t is
     return bn <= nt && need <= ring ? 1 : 0;
 }
 
+// 1 when the tile = 0 all-fp8 launch of (M, N, K) can store its result as fp8 bytes (`c_fp8`): whole tiles of the tile it resolves to
+extern "C" int iir_gemm_fp8_out_supported(int32_t M, int32_t N, int32_t K, int32_t paired) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 128) return 0;
+    const int t = pick_tile(M, N, paired != 0, K);
+    if (t < 1 || t > 5) return 0;
+    return (M % kTiles[t].bm == 0 && N % kTiles[t].bn == 0) ? 1 : 0;
+}
+
 extern "C" int iir_gemm_f16(const iir_gemm_desc* d, void* stream) {
     (void)hipGetLastError();
     Geo g{};
@@ -1318,9 +1334,13 @@ static int fill_gemm_geo(const iir_gemm_desc* d, Geo& g) {
         g.wscale = (const float*)d->wscale;
         g.sk_slabs = nullptr;
     }
+    if (d->c_fp8) {
+        if (d->epi == IIR_EPI_XATTN || d->epi == IIR_EPI_SFT || d->c_f32 || d->Ct || d->ln_stats_out || d->gn_stats_out || d->dtype != IIR_DT_F16) return IIR_EINVAL;
+        g.c_fp8 = 1;
+    }
     g.a_scale = 1.f;
     if (d->a_fp8) {           // A is fp8-E4M3 [M][K] bytes as well (lda in bytes): both operands by 128-byte rows of 128 K values
-        if (!d->wscale || d->K % 128 || d->lda % 16 || (uintptr_t)d->A % 16 || d->ln_stats_in || d->Ct || d->epi == IIR_EPI_XATTN || d->splitk_ws) return IIR_EINVAL;
+        if (!d->wscale || d->K % 128 || d->lda % 16 || (uintptr_t)d->A % 16 || d->ln_stats_in || d->epi == IIR_EPI_XATTN || d->splitk_ws) return IIR_EINVAL;
         g.f8 = 1;
         g.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
         g.K = d->K / 2; g.lda = d->lda / 2;          // counted in 2-byte units from here on: the fp16 staging path unchanged

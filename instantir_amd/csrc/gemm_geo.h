@@ -61,6 +61,7 @@ struct Geo {   // per-launch constants shared by GEMM and CONV paths
     const f16* xa_k[2]; long xa_ldk[2], xa_kb[2];       // K[img][t][head * 64 + d]   (segment 0: text, 1: IP tokens)
     const f16* xa_vt[2]; long xa_ldvt[2], xa_vb[2];     // Vt[head * 64 + d][img * vb + t], readable on [0, roundup8(Tkv))
     int xa_tk[2];                   // 1 <= Tkv[0] <= 80, 1 <= Tkv[1] <= 64
+    int c_fp8;                      // C is a byte matrix of fp8-E4M3 (ldc in bytes): stored by the fast write-out path only
     int f8; float a_scale;          // all-fp8 build: A and W are E4M3 bytes, K / lda counted in 2-byte units; C = (A8 . W8^T) * wscale[n] * a_scale
 };
 

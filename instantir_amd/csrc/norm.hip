@@ -303,7 +303,9 @@ __device__ __forceinline__ void ln_row(const f16* X, long ldx, f16* Y, long ldy,
                 if (sh) f = f * (1.0f + (float)c8[j]) + (float)s8[j];
                 o[j] = (f16)f;
             }
-            if (!transposed) {
+            if (transposed == 2) {          // fp8-E4M3 bytes (the A operand of an all-fp8 GEMM): Y is a byte matrix, ldy in bytes
+                *(long*)((char*)Y + (long)row * ldy + ch * 8) = iir_fp8x8(o);
+            } else if (!transposed) {
                 *(f16x8*)(Y + (long)row * ldy + ch * 8) = o;
             } else {
                 const long col = (long)(row / tr_rows) * tr_bstride + (row % tr_rows);
@@ -525,8 +527,9 @@ extern "C" int iir_layernorm_f16(const void* X, int64_t ldx, void* Y, int64_t ld
     if (!X || !Y || rows <= 0 || C % 8 || C > GN_MAXC || ldx % 8) return IIR_EINVAL;
     if ((shift == nullptr) != (scale == nullptr)) return IIR_EINVAL;
     if (shift && (rows_per_mod <= 0 || ldmod % 8)) return IIR_EINVAL;
-    if (!transposed && ldy % 8) return IIR_EINVAL;
-    if (transposed && tr_rows <= 0) return IIR_EINVAL;
+    if (transposed < 0 || transposed > 2) return IIR_EINVAL;
+    if (transposed != 1 && ldy % 8) return IIR_EINVAL;       // (2: fp8 bytes out, 8 per store)
+    if (transposed == 1 && tr_rows <= 0) return IIR_EINVAL;
     hipLaunchKernelGGL(ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)X, (long)ldx, (f16*)Y,
                        (long)ldy, rows, C, (const f16*)gamma, (const f16*)beta, eps, (const f16*)shift, (const f16*)scale,
                        (long)ldmod, rows_per_mod, transposed, tr_rows, (long)tr_bstride);

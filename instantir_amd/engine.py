@@ -157,6 +157,10 @@ class _Net:
         # producer tags its output tensor with the partials, the GroupNorm that consumes it skips its statistics pass
         self.gn_fuse = os.environ.get("IIR_GN_FUSE", "1") != "0"
         self.xattn_fuse = os.environ.get("IIR_XATTN_FUSE", "1") != "0"      # attn2.to_q + cross-attention as one launch
+        # fp8 build (BASELINE configs[4]): the activations of the transformer linears are STORED as fp8 by the launch that produces
+        # them (LayerNorm, attention, GEGLU) and both operands enter the MFMA as fp8 (`ops.gemm_fp8`): the same operand bytes the
+        # fp8-weight GEMM formed in registers from fp16 activations (identical results), half the 128-byte lines per FLOP
+        self.fp8_act = fp8_linear and os.environ.get("IIR_FP8_ACT", "1") != "0"
         self._pack_encoder(sd)
 
     # ---- weight packing ---------------------------------------------------------------------
@@ -418,6 +422,10 @@ class _Net:
         M = R * T
         m = A.mark()
         fold = lnst is not None
+        if self.fp8_act and not fold and C % 128 == 0 and isinstance(w[p + ".attn1.qkv.w"], ops.Fp8Weight) and h.dtype == F16:
+            self._tblock_fp8(p, h, R, T, heads, st)
+            A.release(m)
+            return
         n = None if fold else A.alloc(M, C)
         # -- self-attention (AttnProcessor2_0, attention_processor.py:370-402)
         qk = A.alloc(M, 2 * C)
@@ -473,6 +481,40 @@ class _Net:
         o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]),
                splitk_ws=None if fold else self._skws, ln_out=None if last else lnst)
         A.release(m)
+
+    def _tblock_fp8(self, p, h, R, T, heads, st):
+        """The block of `_tblock` with fp8 operands on both sides of its six linears (module/min_sdxl.py:541-562; fp8 build only):
+        LayerNorm / attention / GEGLU store their outputs as E4M3 bytes, `ops.gemm_fp8` consumes them."""
+        o, w, A, cfg = self.o, self.w, self.arena, self.cfg
+        C, M = h.shape[1], R * T
+        a8 = lambda rows, cols: A.alloc(rows, cols // 2).view(torch.uint8).view(rows, cols)      # byte matrix in the fp16 arena
+        n8 = a8(M, C)
+        qk = A.alloc(M, 2 * C)
+        vt = A.alloc(C, M)
+        o.layernorm(h, n8, w[p + ".norm1.g"], w[p + ".norm1.b"], 1e-5)
+        wqkv = w[p + ".attn1.qkv.w"]
+        o.gemm_fp8(n8, wqkv, qk, prefetch=self._pf(wqkv), out_t=(vt, 2 * C))
+        at8 = a8(M, C)
+        o.attention(qk[:, :C], at8, [(qk[:, C:], T, vt, T, T)], R, heads, T, q_prescaled=True)
+        o.gemm_fp8(at8, w[p + ".attn1.to_out.0.w"], h, bias=w[p + ".attn1.to_out.0.b"], res=h, prefetch=self._pf(w[p + ".attn1.to_out.0.w"]))
+        if self.cross:
+            q = qk[:, :C]
+            nip, ipad = cfg.num_ip_tokens, (cfg.num_ip_tokens + 7) // 8 * 8
+            kv = st["kv"][p]
+            o.layernorm(h, n8, w[p + ".norm2.g"], w[p + ".norm2.b"], 1e-5)
+            o.gemm_fp8(n8, w[p + ".attn2.to_q.w"], q, prefetch=self._pf(w[p + ".attn2.to_q.w"]))
+            o.attention(q, at8, [(kv["tk"], cfg.text_len, kv["tvt"], kv["tpad"], cfg.text_len), (kv["ipk"], nip, kv["ipvt"], ipad, nip)],
+                        R, heads, T, q_prescaled=True)
+            o.gemm_fp8(at8, w[p + ".attn2.to_out.0.w"], h, bias=w[p + ".attn2.to_out.0.b"], res=h, prefetch=self._pf(w[p + ".attn2.to_out.0.w"]))
+        o.layernorm(h, n8, w[p + ".norm3.g"], w[p + ".norm3.b"], 1e-5)
+        if ops.fp8_out_supported(M, 8 * C, C, True):
+            f8 = a8(M, 4 * C)
+            o.gemm_fp8(n8, w[p + ".ff1.w"], f8, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.w"]))
+            o.gemm_fp8(f8, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]))
+        else:             # ragged tiles (small test geometries): fp16 GEGLU output, converted by the fp8-weight GEMM in registers
+            f = A.alloc(M, 4 * C)
+            o.gemm_fp8(n8, w[p + ".ff1.w"], f, bias=w[p + ".ff1.b"], epi=ops.EPI_GEGLU, prefetch=self._pf(w[p + ".ff1.w"]))
+            o.gemm(f, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h, prefetch=self._pf(w[p + ".ff2.w"]))
 
     def _transformer(self, path, x, depth, R, H, W, st, ada, out=None):
         """Transformer2DModel on the NHWC map x (R*H*W, C).  module/min_sdxl.py:578-595."""

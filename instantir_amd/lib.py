@@ -47,7 +47,7 @@ class GemmDesc(C.Structure):
         ("ln_eps", C.c_float), ("ln_colsum", C.c_void_p),
         ("gn_stats_out", C.c_void_p),
         ("xattn_kv", C.POINTER(AttnKV)), ("xattn_tq", C.c_int32),
-        ("a_fp8", C.c_int32), ("a_scale", C.c_float),
+        ("a_fp8", C.c_int32), ("a_scale", C.c_float), ("c_fp8", C.c_int32),
     ]
 
 
@@ -89,6 +89,7 @@ class AttnDesc(C.Structure):
         ("kv", AttnKV * 2),
         ("causal", C.c_int32),
         ("q_prescaled", C.c_int32),
+        ("o_fp8", C.c_int32),
     ]
 
 
@@ -102,6 +103,7 @@ SIGNATURES = {
     "iir_gemm_pick_tile": (C.c_int, [_I32, _I32, _I32, _I32]),
     "iir_gemm_resolve_tile": (C.c_int, [_P]),
     "iir_gemm_gn_supported": (C.c_int, [_I32, _I32, _I32, _I32]),
+    "iir_gemm_fp8_out_supported": (C.c_int, [_I32, _I32, _I32, _I32]),
     "iir_gemm_tile_bn": (C.c_int, [_I32]),
     "iir_gemm_ln_parts": (C.c_int, [_I32, _I32, _I32]),
     "iir_conv2d_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), _P]),

@@ -133,27 +133,42 @@ def quantize_fp8_rows(w):
     return q, scale
 
 
-def gemm_fp8(a8, w8, out, a_scale=1.0, bias=None, res=None, epi=EPI_PLAIN, act=ACT_NONE, tile=0, prefetch=None):
+_FP8_DTYPES = (torch.float8_e4m3fn, torch.uint8)
+
+
+def gemm_fp8(a8, w8, out, a_scale=1.0, bias=None, res=None, epi=EPI_PLAIN, act=ACT_NONE, tile=0, prefetch=None, out_t=None):
     """out = epi((a8 @ w8.q.T) * w8.scale[None, :] * a_scale ...): BOTH operands fp8-E4M3 (`iir_gemm_desc.a_fp8`).
     a8 (M, K) torch.float8_e4m3fn (or its bytes) view with a 16-byte-aligned row stride, K % 128 == 0; w8 an `Fp8Weight`;
     out / bias / res fp16.  One K tile is 128 K values = the same 128-byte rows the fp16 path stages for 64."""
     if not isinstance(w8, Fp8Weight):
         raise ValueError("gemm_fp8: w8 must be an Fp8Weight")
-    if a8.dtype not in (torch.float8_e4m3fn, torch.uint8) or a8.dim() != 2 or a8.stride(1) != 1 or not a8.is_cuda:
+    if a8.dtype not in _FP8_DTYPES or a8.dim() != 2 or a8.stride(1) != 1 or not a8.is_cuda:
         raise ValueError("gemm_fp8: a8 must be a 2-D CUDA view of torch.float8_e4m3fn (or its bytes) with contiguous rows")
     M, K = a8.shape
     N = w8.q.shape[0]
     if w8.q.shape[1] != K or K % 128 or a8.stride(0) % 16:
         raise ValueError("gemm_fp8: K must match, K % 128 == 0, row stride % 16 == 0")
     dt = torch.float16
-    _chk2d(out, "out", dt)
-    n_out = N if epi == EPI_PLAIN else N // 2
+    c_fp8 = out.dtype in _FP8_DTYPES            # the output is the NEXT all-fp8 GEMM's A operand: stored as E4M3 bytes (fp16 rounding first)
+    if c_fp8:
+        if out.dim() != 2 or out.stride(1) != 1 or out.stride(0) % 8 or not out.is_cuda:
+            raise ValueError("gemm_fp8: an fp8 `out` needs contiguous rows with a stride % 8 == 0")
+    else:
+        _chk2d(out, "out", dt)
+    n_out = (N if epi == EPI_PLAIN else N // 2) if out_t is None else out_t[1]
     if out.shape != (M, n_out):
         raise ValueError(f"out shape {tuple(out.shape)} != {(M, n_out)}")
     for t_, n_ in ((bias, "bias"), (res, "res")):
         if t_ is not None and t_.dtype != dt:
             raise ValueError(f"{n_}: fp16 expected")
     d = L.GemmDesc()
+    d.c_fp8 = int(c_fp8)
+    if out_t is not None:                      # columns >= tr_from leave transposed (the V third of q|k|v), as in `gemm`
+        ct, tr_from = out_t
+        _chk2d(ct, "out_t", dt)
+        if c_fp8 or ct.shape[0] < N - tr_from or ct.shape[1] < M:
+            raise ValueError("out_t: fp16 (N - tr_from, M), with an fp16 `out`")
+        d.Ct, d.ldct, d.tr_from = ct.data_ptr(), ct.stride(0), tr_from
     d.A, d.lda = a8.data_ptr(), a8.stride(0)
     d.W, d.wscale = w8.q.data_ptr(), w8.scale.data_ptr()
     d.C, d.ldc = out.data_ptr(), out.stride(0)
@@ -170,6 +185,11 @@ def gemm_fp8(a8, w8, out, a_scale=1.0, bias=None, res=None, epi=EPI_PLAIN, act=A
     with _Timed("gemm_kernel<%s,gemm-f8>" % _TILE_NAMES[t_name % 10], 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * n_out * (2 if res is not None else 1)):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out
+
+
+def fp8_out_supported(M, N, K, paired=False):
+    """Can the all-fp8 launch of (M, N, K) store its result as fp8 bytes (an fp8 `out` of `gemm_fp8`)?"""
+    return bool(L.load().iir_gemm_fp8_out_supported(M, N, K, int(paired)))
 
 
 def quantize_fp8_tensor(x):
@@ -393,8 +413,14 @@ def attn_q_factor(scale=0.125):
 def attention(q, o, kv, batch, heads, Tq, scale=0.125, causal=False, q_prescaled=False):
     """q, o: 2-D views (batch*Tq, heads*64).  kv: list of 1-2 tuples (k2d, k_batch_rows, vt2d, vt_batch_stride, Tkv):
     k2d (batch*k_batch_rows, heads*64) view, vt2d (heads*64, cols) view with batch b starting at column b*vt_batch_stride."""
-    _chk2d(q, "q"); _chk2d(o, "o")
+    _chk2d(q, "q")
     d = L.AttnDesc()
+    if o.dtype in _FP8_DTYPES:          # the output feeds an all-fp8 `to_out` GEMM: E4M3 bytes (rounded to fp16 first)
+        if o.dim() != 2 or o.stride(1) != 1 or o.stride(0) % 4 or not o.is_cuda:
+            raise ValueError("attention: an fp8 `o` needs contiguous rows with a stride % 4 == 0")
+        d.o_fp8 = 1
+    else:
+        _chk2d(o, "o")
     d.Q, d.ldq, d.q_batch_stride = q.data_ptr(), q.stride(0), Tq * q.stride(0)
     d.O, d.ldo, d.o_batch_stride = o.data_ptr(), o.stride(0), Tq * o.stride(0)
     d.batch, d.heads, d.Tq, d.nseg, d.scale = batch, heads, Tq, len(kv), scale
@@ -458,7 +484,15 @@ def groupnorm(x, out, R, HW, gamma, beta, eps, silu, groups=32, ws=None, partial
 
 def layernorm(x, out, gamma=None, beta=None, eps=1e-5, shift=None, scale=None, rows_per_mod=1, transposed=False,
               tr_rows=1, tr_bstride=0):
-    _chk2d(x, "x"); _chk2d(out, "out")
+    """`out` of dtype torch.float8_e4m3fn (or uint8): the normalised rows are stored as E4M3 bytes (rounded to fp16 first) -- the
+    A operand of an all-fp8 GEMM (`gemm_fp8`)."""
+    _chk2d(x, "x")
+    if out.dtype in (torch.float8_e4m3fn, torch.uint8):
+        if transposed or out.dim() != 2 or out.stride(1) != 1 or out.stride(0) % 8 or not out.is_cuda or out.shape != x.shape:
+            raise ValueError("layernorm: an fp8 `out` needs x's shape, contiguous rows with a stride % 8 == 0, no transposition")
+        transposed = 2
+    else:
+        _chk2d(out, "out")
     rows, Cc = x.shape
     ldmod = shift.stride(0) if shift is not None else 0
     L.check(L.load().iir_layernorm_f16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, Cc, _p(gamma),

@@ -813,3 +813,55 @@ def test_gemm_fp8_both_operands(dev, M, N, K, mode, tile):
     _close(out, want.float(), rtol=2e-3, atol=2e-3, what="fp8 x fp8 gemm")
     with pytest.raises(ValueError):
         ops.gemm_fp8(a8[:, :K - 64], ops.Fp8Weight(q[:, :K - 64].contiguous(), sc), out)       # K % 128
+
+
+def _fp8_bytes_of(x16):
+    """What `iir_fp8x8` stores for fp16 values: E4M3, round to nearest even, saturating."""
+    return x16.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+
+
+def test_producers_store_fp8_operands(dev):
+    """LayerNorm, attention and the GEGLU epilogue can store their result as E4M3 bytes (the A operand of the next all-fp8 GEMM):
+    exactly the fp16 result of the same launch, converted as the fp8-weight GEMM converts its activation fragments."""
+    from instantir_amd import ops
+    from instantir_amd.packing import pair_rows
+    g = torch.Generator().manual_seed(5)
+    M, C = 512, 640
+    x = (_rand(g, M, C).float() * 3 + torch.randn(M, 1, generator=g)).half().to(dev)
+    gam, bet = (1 + 0.2 * torch.randn(C, generator=g)).half().to(dev), (0.3 * torch.randn(C, generator=g)).half().to(dev)
+    y16 = torch.empty(M, C, dtype=torch.half, device=dev)
+    y8 = torch.zeros(M, C, dtype=torch.uint8, device=dev)
+    ops.layernorm(x, y16, gam, bet, 1e-5)
+    ops.layernorm(x, y8, gam, bet, 1e-5)
+    assert torch.equal(y8.view(torch.float8_e4m3fn).float(), _fp8_bytes_of(y16).float()), "LayerNorm fp8 store"
+    # attention (self, and text + IP), fp8 output
+    B, heads, T = 2, 4, 256
+    Ch = heads * 64
+    q, k, v = _rand(g, B * T, Ch).to(dev), _rand(g, B * T, Ch).to(dev), _rand(g, B, T, Ch)
+    vt = torch.cat([v[b].T for b in range(B)], 1).contiguous().to(dev)
+    o16 = torch.empty(B * T, Ch, dtype=torch.half, device=dev)
+    o8 = torch.zeros(B * T, Ch, dtype=torch.uint8, device=dev)
+    for segs in ([(k, T, vt, T, T)], [(k[:2 * 77 * 0 + B * T], T, vt, T, 77), (k, T, vt, T, 64)]):
+        ops.attention(q, o16, segs, B, heads, T)
+        ops.attention(q, o8, segs, B, heads, T)
+        assert torch.equal(o8.view(torch.float8_e4m3fn).float(), _fp8_bytes_of(o16).float()), "attention fp8 store"
+    # GEGLU projection with fp8 operands AND an fp8 result; q|k|v with a transposed V third
+    K, N = 640, 2560
+    a8, sa = ops.quantize_fp8_tensor(_rand(g, M, K).to(dev))
+    w, b = _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
+    wq = ops.Fp8Weight(*ops.quantize_fp8_rows(pair_rows(w[:N // 2], w[N // 2:]).to(dev)))
+    bp = pair_rows(b[:N // 2], b[N // 2:]).to(dev)
+    f16o = torch.empty(M, N // 2, dtype=torch.half, device=dev)
+    f8o = torch.zeros(M, N // 2, dtype=torch.uint8, device=dev)
+    ops.gemm_fp8(a8, wq, f16o, a_scale=sa, bias=bp, epi=ops.EPI_GEGLU)
+    ops.gemm_fp8(a8, wq, f8o, a_scale=sa, bias=bp, epi=ops.EPI_GEGLU)
+    assert torch.equal(f8o.view(torch.float8_e4m3fn).float(), _fp8_bytes_of(f16o).float()), "GEGLU fp8 store"
+    w3 = ops.Fp8Weight(*ops.quantize_fp8_rows(_rand(g, 3 * K, K, scale=K ** -0.5).to(dev)))
+    full = torch.empty(M, 3 * K, dtype=torch.half, device=dev)
+    qk, vtr = torch.empty(M, 2 * K, dtype=torch.half, device=dev), torch.zeros(K, M, dtype=torch.half, device=dev)
+    ops.gemm_fp8(a8, w3, full, a_scale=sa)
+    ops.gemm_fp8(a8, w3, qk, a_scale=sa, out_t=(vtr, 2 * K))
+    torch.cuda.synchronize()
+    assert torch.equal(qk, full[:, :2 * K]) and torch.equal(vtr, full[:, 2 * K:].T.contiguous())
+    with pytest.raises(ValueError):
+        ops.layernorm(x, y8[:, :C - 8], gam, bet, 1e-5)
