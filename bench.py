@@ -473,7 +473,10 @@ def config4(args, rank, world, local, dev):
             "metric": "restoration steps/sec, LCM single-step previewer path at 1024x1024 (BASELINE configs[4]; not the headline metric)",
             "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8-e4m3 weights + in-kernel fp8 activations on the transformer linears (fp32 accumulate); fp16 elsewhere" if not args.fp16 else "f16 (fp32 accumulate)",
+            "dtype": ("f16 (fp32 accumulate)" if args.fp16 else
+                      ("fp8-e4m3 weights AND activations on the transformer linears (activations stored as fp8 by the producing launch; fp32 accumulate); fp16 elsewhere"
+                       if net.fp8_act else
+                       "fp8-e4m3 weights, fp16 activations converted to fp8 in the GEMM's registers, on the transformer linears (fp32 accumulate); fp16 elsewhere")),
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[4]: LCM single step (t = 999, guidance 1.0), previewer LoRA merged, {B} images/GPU at "
                                    f"{args.size}x{args.size}, one UNet pass of {B} rows + LCM step per step" + (" [TINY DEBUG GEOMETRY]" if args.tiny else ""),
