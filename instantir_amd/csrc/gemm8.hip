@@ -33,7 +33,9 @@ constexpr int PF_TOUCHES = 2;
 // piece per sub-phase (activations in sub-phases 0..3, weights behind them); 2 = as 1, and waves 4-7 (the second wave of every
 // SIMD) issue a sub-phase's piece AFTER its MFMAs instead of before them, so the two waves of a SIMD do not sit in the
 // (~70-125 cycle) LDS-DMA issue at the same moment with the matrix pipe idle behind them
-template <int BN, int V>
+// F8: both operands fp8-E4M3 (gemm_conv.hip, same scheme: K counted in 2-byte units by the host, two fp8 MFMAs per 16-byte fragment pair,
+// wscale[n] * a_scale in the epilogue)
+template <int BN, int V, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
     using E = f16;
     using E4 = f16x4;
@@ -168,7 +170,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[s][j], ac[s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr (F8) {
+                        typedef long l2 __attribute__((ext_vector_type(2)));
+                        const l2 b2 = __builtin_bit_cast(l2, bfr[s][j]), a2 = __builtin_bit_cast(l2, ac[s]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[0], a2[0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[1], a2[1], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[s][j], ac[s], acc[i][j], 0, 0, 0);
+                    }
+                }
             __builtin_amdgcn_s_setprio(0);
             if (i == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Y(t): every wave holds its weight fragments
             if (late) piece(i);
@@ -200,12 +211,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
         }
     };
     // column constants of this lane's NI column quads
-    f32x4 c1v[NI];
+    f32x4 c1v[NI], scv[F8 ? NI : 1];
     E4 c0v[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int nc = n0 + wn * WN + j * 16 + fq * 4;
         c1v[j] = g.ln_in ? *(const f32x4*)(g.ln_colsum + nc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (F8) scv[j] = *(const f32x4*)(g.wscale + nc) * g.a_scale;
         if (g.bias) c0v[j] = *(const E4*)(g.bias + nc);
         else for (int t = 0; t < 4; ++t) c0v[j][t] = (E)0.f;
     }
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
             for (int j = 0; j < NI; ++j) {
                 float a[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) a[t] = fmaf(acc[i][j][t], rs.x, fmaf(rs.y, c1v[j][t], (float)c0v[j][t]));
+                for (int t = 0; t < 4; ++t) a[t] = fmaf(F8 ? acc[i][j][t] * scv[F8 ? j : 0][t] : acc[i][j][t], rs.x, fmaf(rs.y, c1v[j][t], (float)c0v[j][t]));
                 if (!paired) {
                     if (g.act == IIR_ACT_SILU) for (int t = 0; t < 4; ++t) a[t] = silu_f(a[t]);
                     else if (g.act == IIR_ACT_GELU) for (int t = 0; t < 4; ++t) a[t] = gelu_erf_f(a[t]);
@@ -278,13 +290,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const Geo g) {
             } else {
                 for (int t = 0; t < 8; ++t) o[t] = (E)((float)v[t] * g.out_scale);
             }
-            iir::store16(g.C, (m * g.ldc + no_tile + cc * 8) * 2, o, g.st_wt != 0);
+            if (g.c_fp8) *(long*)((char*)g.C + m * g.ldc + no_tile + cc * 8) = iir_fp8x8(o);      // the next all-fp8 GEMM's A operand
+            else iir::store16(g.C, (m * g.ldc + no_tile + cc * 8) * 2, o, g.st_wt != 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA touches must land before the LDS is released
 }
 
-template <int BN, int V>
+template <int BN, int V, bool F8 = false>
 int launch8v(const Geo& g0, hipStream_t stream) {
     constexpr int BM = 256;
     Geo g = g0;
@@ -305,15 +318,16 @@ int launch8v(const Geo& g0, hipStream_t stream) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (attr_dev != dev) {
-        if (hipFuncSetAttribute((const void*)gemm8_kernel<BN, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IIR_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)gemm8_kernel<BN, V, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IIR_ELAUNCH;
         attr_dev = dev;
     }
-    iir_launch(gemm8_kernel<BN, V>, dim3(8 * g.rm * g.rn), dim3(512), lds, stream, g);
+    iir_launch(gemm8_kernel<BN, V, F8>, dim3(8 * g.rm * g.rn), dim3(512), lds, stream, g);
     return iir_launch_status();
 }
 
 template <int BN>
 int launch8(const Geo& g, hipStream_t stream) {
+    if (g.f8) return launch8v<BN, 0, true>(g, stream);
     static const int v = getenv("IIR_G8V") ? atoi(getenv("IIR_G8V")) : 0;
     return v == 2 ? launch8v<BN, 2>(g, stream) : v == 1 ? launch8v<BN, 1>(g, stream) : launch8v<BN, 0>(g, stream);
 }
@@ -324,11 +338,13 @@ namespace iir {
 
 bool gemm8_covers(const Geo& g, int bn) {
     if (bn != 320 && bn != 256) return false;
-    if (g.dtype != IIR_DT_F16 || g.c_f32 || g.ln_out || g.gn_out || g.splitk == 2 || g.wscale || g.rowbias || g.c_fp8 || g.f8 || g.xa_on) return false;
+    if (g.dtype != IIR_DT_F16 || g.c_f32 || g.ln_out || g.gn_out || g.splitk == 2 || (g.wscale && !g.f8) || g.rowbias || g.xa_on) return false;
+    if (g.f8 && (g.ln_in || g.Ct || bn != 320)) return false;            // all-fp8 form: the GEGLU / plain projections of the fp8 build
+    if (g.c_fp8 && (g.ldc % 8 || (uintptr_t)g.C % 8)) return false;
     if (g.Ct && (g.epi != IIR_EPI_PLAIN || g.res || g.tr_from % bn || !g.ct_vec)) return false;      // transposed column range: whole tiles only
     if (g.epi != IIR_EPI_PLAIN && g.epi != IIR_EPI_GEGLU) return false;
     if (g.M % 256 || g.N % bn || g.K % 64 || g.K < 128) return false;
-    if (!g.c_vec || (g.res && g.epi == IIR_EPI_PLAIN && !g.r_vec)) return false;
+    if ((!g.c_vec && !g.c_fp8) || (g.res && g.epi == IIR_EPI_PLAIN && !g.r_vec)) return false;
     if (g.lda % 8 || ((uintptr_t)g.A % 16) || ((uintptr_t)g.W % 16)) return false;
     if (g.bias && ((uintptr_t)g.bias % 8)) return false;
     if (g.ln_in && g.ln_parts > 8) return false;

@@ -1147,7 +1147,7 @@ bool uses_splitk(int M, int N, int K, long ws_bytes) {
 
 bool gemm8_auto(const Geo& g, bool conv) {
     static const bool g8_on = !(getenv("IIR_G8") && atoi(getenv("IIR_G8")) == 0);
-    return g8_on && !conv && g.K >= 640 && (long)(g.M / 256) * (g.N / 320) >= 256 && iir::gemm8_covers(g, 320);
+    return g8_on && !conv && (g.f8 ? 2 * g.K : g.K) >= 640 && (long)(g.M / 256) * (g.N / 320) >= 256 && iir::gemm8_covers(g, 320);
 }
 
 int dispatch(const Geo& g, bool conv, int tile, hipStream_t stream) {

@@ -182,7 +182,10 @@ def gemm_fp8(a8, w8, out, a_scale=1.0, bias=None, res=None, epi=EPI_PLAIN, act=A
     if prefetch is not None:
         d.prefetch, d.prefetch_bytes = prefetch
     t_name = tile if tile else auto_tile(M, N, epi != EPI_PLAIN, K)
-    with _Timed("gemm_kernel<%s,gemm-f8>" % _TILE_NAMES[t_name % 10], 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * n_out * (2 if res is not None else 1)):
+    cls = "gemm_kernel<%s,gemm-f8>" % _TILE_NAMES[t_name % 10]
+    if tile == 91 or (PROFILER is not None and tile == 0 and L.load().iir_gemm_resolve_tile(C.byref(d)) == 91):
+        cls = "gemm8_kernel<256x320,gemm-f8>"
+    with _Timed(cls, 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * n_out * (2 if res is not None else 1)):
         L.check(L.load().iir_gemm_f16(C.byref(d), _stream()), "iir_gemm_f16")
     return out
 

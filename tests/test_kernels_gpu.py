@@ -784,7 +784,9 @@ def test_gemm_cross_attention_epilogue(dev, R, T, heads, K, tk, ti, fold):
 # ---- round 3: both operands in fp8 (iir_gemm_desc.a_fp8) ---------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,mode,tile", [(256, 320, 256, "plain", 0), (2048, 1280, 1280, "res", 0), (2048, 1280, 5120, "plain", 0),
                                              (8192, 640, 640, "res", 0), (512, 2560, 640, "geglu", 0), (300, 160, 384, "plain", 25),
-                                             (4096, 1280, 1280, "plain", 21), (2048, 1280, 1280, "plain", 55)])
+                                             (4096, 1280, 1280, "plain", 21), (2048, 1280, 1280, "plain", 55),
+                                             (512, 640, 256, "geglu", 91), (256, 320, 256, "plain", 91), (512, 640, 384, "res", 91),
+                                             (4096, 10240, 1280, "geglu", 0)])      # 91 / the last one: the 8-wave 256 x 320 kernel
 def test_gemm_fp8_both_operands(dev, M, N, K, mode, tile):
     """A and W as E4M3 bytes, 128 K values per K tile (two fp8 MFMAs on the 16 bytes a lane reads).  Exact reference: the same
     bytes dequantised, multiplied in fp64 -- products of fp8 values are exact in fp32, only the accumulation order differs."""
