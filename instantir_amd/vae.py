@@ -45,6 +45,7 @@ class HipVAE:
         self.tile_sample_size = 1024         # AutoencoderKL config.sample_size (autoencoder_kl.py:117-124)
         self.tile_overlap_factor = 0.25      # autoencoder_kl.py:124
         self.use_tiling = False              # `vae.enable_tiling()` (autoencoder_kl.py:130-143)
+        self.use_slicing = False             # `vae.enable_slicing()` (autoencoder_kl.py:145-157)
         self.dtype_name = "bf16" if dtype == torch.bfloat16 else "fp16"
         F16 = dtype          # (the rest of this class allocates its 16-bit tensors as `F16`: the VAE's element type)
         self._E = dtype
@@ -82,6 +83,13 @@ class HipVAE:
 
     def disable_tiling(self):
         self.enable_tiling(False)
+
+    def enable_slicing(self):
+        """autoencoder_kl.py:145-157: batches are encoded / decoded one image at a time (activation memory of ONE image)."""
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
 
     @property
     def tile_latent_min_size(self):
@@ -229,7 +237,11 @@ class HipVAE:
         z = latents.to(self.device, torch.float32) / self.cfg.scaling_factor
         tiled = self.use_tiling if tiled is None else tiled
         big = z.shape[-1] > self.tile_latent_min_size or z.shape[-2] > self.tile_latent_min_size
-        img = self.decode_tiled(z, self.tile_sample_size, self.tile_overlap_factor) if tiled and big else self.decode(z)
+        one = lambda zz: self.decode_tiled(zz, self.tile_sample_size, self.tile_overlap_factor) if tiled and big else self.decode(zz)
+        if self.use_slicing and z.shape[0] > 1:          # autoencoder_kl.py:300-302: every slice takes the (tiled or plain) path on its own
+            img = torch.cat([one(zz) for zz in z.split(1)])
+        else:
+            img = one(z)
         if not torch.isfinite(img).all():
             raise FloatingPointError("VAE decode produced non-finite pixels (activation overflow): this build stores VAE "
                                      f"activations as {self.dtype_name}; see DESIGN.md section 7")
@@ -250,7 +262,12 @@ class HipVAE:
         Returns the UNscaled latent mean + std * eps (fp32)."""
         image = image.to(self.device, torch.float32).contiguous()
         big = image.shape[-1] > self.tile_sample_size or image.shape[-2] > self.tile_sample_size
-        mom = self.moments_tiled(image, self.tile_sample_size, self.tile_overlap_factor) if self.use_tiling and big else self.moments(image)
+        if self.use_tiling and big:
+            mom = self.moments_tiled(image, self.tile_sample_size, self.tile_overlap_factor)
+        elif self.use_slicing and image.shape[0] > 1:    # autoencoder_kl.py:256-258
+            mom = torch.cat([self.moments(x1) for x1 in image.split(1)])
+        else:
+            mom = self.moments(image)
         mean, logvar = mom[:, :4], mom[:, 4:]
         std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))           # module/diffusers_vae/vae.py:774-777,792
         return mean + std * eps.to(self.device, torch.float32)

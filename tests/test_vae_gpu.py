@@ -285,3 +285,22 @@ def test_vae_tiled_decode_full_size_properties(dev):
     alone = (hv.decode(zz[:, :, :128, :128].contiguous()) / 2 + 0.5).clamp(0, 1)
     assert torch.equal(img[:, :, :768, :768], alone[:, :, :768, :768])
 
+
+
+def test_vae_slicing_is_per_image_and_changes_nothing(vae_env):
+    """`vae.enable_slicing()` (module/diffusers_vae/autoencoder_kl.py:145-157,256-258,300-302): a batch goes through encoder /
+    decoder one image at a time.  Every image's result must equal the batched one bit for bit (no cross-image arithmetic exists)."""
+    vc, sd, hv = vae_env
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(3, 4, 8, 8, generator=g) * vc.scaling_factor
+    img = torch.rand(3, 3, 64, 64, generator=g) * 2 - 1
+    eps = torch.randn(3, 4, 8, 8, generator=g)
+    d0, e0 = hv.decode_latent(z, "pt").clone(), hv.encode(img, eps).clone()
+    hv.enable_slicing()
+    try:
+        assert hv.use_slicing
+        d1, e1 = hv.decode_latent(z, "pt"), hv.encode(img, eps)
+    finally:
+        hv.disable_slicing()
+    assert not hv.use_slicing
+    assert torch.equal(d0, d1) and torch.equal(e0, e1)
