@@ -54,10 +54,21 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_state_dict(sd: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 1 << 30) -> Dict[str, torch.Tensor]:
-    """In-place broadcast of every tensor of `sd` (same names/shapes on all ranks) in flat buckets."""
+def broadcast_state_dict(sd: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 1 << 30, algo: str = None) -> Dict[str, torch.Tensor]:
+    """In-place distribution of every tensor of `sd` (same names / shapes on all ranks) from rank `src`, in flat buckets.
+    algo "broadcast" (default): one `dist.broadcast` per bucket (a ring / tree out of one GPU).  "scatter_allgather"
+    (`IIR_BCAST_ALGO=scatter_allgather`): the source SCATTERS one N-th of a bucket to every rank -- on an MI355X node that is seven
+    different xGMI links at once, point to point -- and an all-gather completes it, so no link carries more than ~2/N of the
+    bucket out of the source.  Opt-in until it has been timed on an 8-GPU node (neither form has: this pipeline's boxes have one
+    GPU); both are covered by the world-size-2 gloo test.  One-time set-up traffic (the weights are generated or read once, on
+    rank 0); no collective exists on the per-step path."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return sd
+    import os
+    algo = algo or os.environ.get("IIR_BCAST_ALGO", "broadcast")
+    if algo not in ("scatter_allgather", "broadcast"):
+        raise ValueError(f"unknown weight distribution algorithm {algo!r}")
+    world, rank = dist.get_world_size(), dist.get_rank()
     names = sorted(sd)
     bucket: List[str] = []
     size = 0
@@ -66,8 +77,21 @@ def broadcast_state_dict(sd: Dict[str, torch.Tensor], src: int = 0, bucket_bytes
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat([sd[n].reshape(-1) for n in bucket])
-        dist.broadcast(flat, src)
+        parts = [sd[n].reshape(-1) for n in bucket]
+        total = sum(p_.numel() for p_ in parts)
+        if algo == "broadcast":
+            flat = torch.cat(parts)
+            dist.broadcast(flat, src)
+        else:
+            chunk = (total + world - 1) // world
+            flat = torch.empty(chunk * world, dtype=parts[0].dtype, device=parts[0].device)
+            views = [flat[r * chunk:(r + 1) * chunk] for r in range(world)]
+            if rank == src:
+                torch.cat(parts, out=flat[:total])
+                flat[total:].zero_()
+            mine = torch.empty(chunk, dtype=flat.dtype, device=flat.device)
+            dist.scatter(mine, scatter_list=views if rank == src else None, src=src)
+            dist.all_gather(views, mine)
         off = 0
         for n in bucket:
             k = sd[n].numel()

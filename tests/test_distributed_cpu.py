@@ -24,11 +24,15 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(100 + rank)          # ranks start with DIFFERENT tensors
     sd = {"a.weight": torch.randn(300, 7, generator=g).half(), "b.bias": torch.randn(11, generator=g).half(),
           "c.f32": torch.randn(5, 5, generator=g)}
-    parallel.broadcast_state_dict(sd, 0, bucket_bytes=1024)
     ref = torch.Generator().manual_seed(100)
     want = {"a.weight": torch.randn(300, 7, generator=ref).half(), "b.bias": torch.randn(11, generator=ref).half(),
             "c.f32": torch.randn(5, 5, generator=ref)}
-    same = all(torch.equal(sd[k], want[k]) for k in want)
+    same = True
+    for algo in ("scatter_allgather", "broadcast"):       # both forms of the one-time weight distribution (odd sizes: padded chunks)
+        mine = {k: v.clone() for k, v in sd.items()}
+        parallel.broadcast_state_dict(mine, 0, bucket_bytes=1024, algo=algo)
+        same = same and all(torch.equal(mine[k], want[k]) for k in want)
+    parallel.broadcast_state_dict(sd, 0, bucket_bytes=1024)
     lo, hi = parallel.shard_range(9, r, w)
     mx = parallel.max_over_ranks(1.0 + r, dev)
     per_rank = parallel.gather_floats(10.0 + r, dev)       # bench.py's ms_per_step_by_rank
