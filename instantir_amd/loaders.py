@@ -165,13 +165,10 @@ def _read_json(path):
         return json.load(f)
 
 
-def unet_config_from_dir(model_dir: str) -> UNetConfig:
-    """`<model_dir>/unet/config.json` (diffusers `UNet2DConditionModel` config) -> UNetConfig; SDXL-base values when the
-    file is absent.  Only SDXL-family layouts are accepted: DownBlock2D first, head_dim 64, text_time addition embedding."""
-    path = os.path.join(model_dir, "unet", "config.json")
-    if not os.path.isfile(path):
-        return UNetConfig.sdxl()
-    c = _read_json(path)
+def unet_config_from_dict(c) -> UNetConfig:
+    """A diffusers `UNet2DConditionModel` config (dict, or the `.config` object of a module) -> UNetConfig.  Only SDXL-family
+    layouts are accepted: DownBlock2D first, head_dim 64, text_time addition embedding."""
+    c = dict(c)
     boc = tuple(c["block_out_channels"])
     types = c.get("down_block_types", ["DownBlock2D"] + ["CrossAttnDownBlock2D"] * (len(boc) - 1))
     tl = c.get("transformer_layers_per_block", 1)
@@ -181,9 +178,9 @@ def unet_config_from_dir(model_dir: str) -> UNetConfig:
     ahd = [ahd] * len(boc) if isinstance(ahd, int) else list(ahd)       # SDXL stores the HEAD COUNT per block here
     for i, d in enumerate(depth):
         if d > 0 and boc[i] // ahd[i] != 64:
-            raise ValueError(f"unet/config.json: block {i} has head_dim {boc[i] // ahd[i]}; the HIP attention kernel is head_dim 64")
+            raise ValueError(f"unet config: block {i} has head_dim {boc[i] // ahd[i]}; the HIP attention kernel is head_dim 64")
     if c.get("addition_embed_type", "text_time") != "text_time":
-        raise ValueError("unet/config.json: only addition_embed_type 'text_time' (SDXL) is supported")
+        raise ValueError("unet config: only addition_embed_type 'text_time' (SDXL) is supported")
     ate = c.get("addition_time_embed_dim", 256)
     base = UNetConfig.sdxl()
     return dataclasses.replace(
@@ -193,14 +190,22 @@ def unet_config_from_dir(model_dir: str) -> UNetConfig:
         norm_groups=c.get("norm_num_groups", 32))
 
 
-def vae_config_from_dir(model_dir: str) -> VAEConfig:
-    path = os.path.join(model_dir, "vae", "config.json")
-    if not os.path.isfile(path):
-        return VAEConfig.sdxl()
-    c = _read_json(path)
+def unet_config_from_dir(model_dir: str) -> UNetConfig:
+    """`<model_dir>/unet/config.json` -> UNetConfig; SDXL-base values when the file is absent."""
+    path = os.path.join(model_dir, "unet", "config.json")
+    return unet_config_from_dict(_read_json(path)) if os.path.isfile(path) else UNetConfig.sdxl()
+
+
+def vae_config_from_dict(c) -> VAEConfig:
+    c = dict(c)
     return VAEConfig(in_channels=c.get("in_channels", 3), latent_channels=c.get("latent_channels", 4),
                      block_out_channels=tuple(c["block_out_channels"]), layers_per_block=c.get("layers_per_block", 2),
                      norm_groups=c.get("norm_num_groups", 32), scaling_factor=c.get("scaling_factor", 0.13025))
+
+
+def vae_config_from_dir(model_dir: str) -> VAEConfig:
+    path = os.path.join(model_dir, "vae", "config.json")
+    return vae_config_from_dict(_read_json(path)) if os.path.isfile(path) else VAEConfig.sdxl()
 
 
 def resampler_config_from_state(image_proj: Dict[str, torch.Tensor], seq_len: int = 257) -> ResamplerConfig:

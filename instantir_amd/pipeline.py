@@ -30,7 +30,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 
 from . import ops
-from .config import UNetConfig
+from .config import UNetConfig, VAEConfig
 from .engine import CPAD, F16, HipAggregator, HipUNet
 from .schedulers import DDIMScheduler, DDPMScheduler, LCMSingleStepScheduler  # noqa: F401
 from .weights import LCM_LORA_MODULES, PREVIEWER_LORA_MODULES, lora_target
@@ -176,6 +176,64 @@ class InstantIRPipeline:
             tok.append(t)
         return cls(cfg, unet_sd, scheduler=kwargs.get("scheduler"), vae=vae, device=device, text_encoder=enc[0],
                    text_encoder_2=enc[1], tokenizer=tok[0], tokenizer_2=tok[1])
+
+    @classmethod
+    def from_modules(cls, vae=None, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, unet=None, scheduler=None,
+                     aggregator=None, force_zeros_for_empty_prompt=True, add_watermarker=None, feature_extractor=None,
+                     image_encoder=None, device="cuda:0", unet_config=None, vae_config=None):
+        """The reference's own constructor signature (pipelines/sdxl_instantir.py:303-322): build the pipeline from module OBJECTS
+        somebody else loaded -- anything with `.state_dict()` (diffusers / transformers modules, or plain dicts of their
+        tensors) and, where geometry is not implied by the tensors, a `.config` (mapping or attribute object; `unet_config=` /
+        `vae_config=` override it).  `aggregator=None` = `Aggregator.from_unet(unet)` (:319-320); tokenizers may be transformers
+        tokenizers or callables `list[str] -> (B, 77) ids`; `image_encoder` a `HipDinov2` / `HipCLIPVision` or a module of one
+        of those architectures (DINOv2 unless its tensors say CLIP).  `add_watermarker` / `feature_extractor` are accepted and
+        unused (no watermarking; image pre-processing is `encoders.preprocess_*`), `force_zeros_for_empty_prompt` must stay True
+        (the only value the reference's loaders produce)."""
+        from . import loaders
+        from .encoders import HipCLIPText, HipCLIPVision, HipDinov2
+        from .vae import HipVAE
+        if unet is None:
+            raise ValueError("from_modules: `unet` is required")
+        if not force_zeros_for_empty_prompt:
+            raise NotImplementedError("force_zeros_for_empty_prompt=False is not supported")
+
+        def tensors(m):
+            return dict(m) if isinstance(m, dict) else dict(m.state_dict())
+
+        def conf(m):
+            c = getattr(m, "config", None)
+            if c is None:
+                return None
+            return dict(c) if hasattr(c, "keys") else {k: getattr(c, k) for k in dir(c) if not k.startswith("_") and not callable(getattr(c, k))}
+
+        cfg = unet_config or (loaders.unet_config_from_dict(conf(unet)) if conf(unet) else UNetConfig.sdxl())
+        hv = vae
+        if vae is not None and not isinstance(vae, HipVAE):
+            vc = vae_config or (loaders.vae_config_from_dict(conf(vae)) if conf(vae) else VAEConfig.sdxl())
+            hv = HipVAE(vc, tensors(vae), device)
+        encs = []
+        for m, default_act in ((text_encoder, "quick_gelu"), (text_encoder_2, "gelu")):
+            if m is None or isinstance(m, HipCLIPText):
+                encs.append(m)
+                continue
+            c = conf(m) or {}
+            encs.append(HipCLIPText(tensors(m), device, hidden_act=c.get("hidden_act", default_act), eos_token_id=c.get("eos_token_id", 2),
+                                    eps=c.get("layer_norm_eps", 1e-5)))
+        toks = []
+        for t in (tokenizer, tokenizer_2):
+            if t is not None and hasattr(t, "model_max_length"):          # a transformers tokenizer
+                t = (lambda tk_: (lambda texts: tk_(texts, padding="max_length", max_length=tk_.model_max_length, truncation=True,
+                                                    return_tensors="pt").input_ids))(t)
+            toks.append(t)
+        ie = image_encoder
+        if ie is not None and not isinstance(ie, (HipDinov2, HipCLIPVision)):
+            sd_ie = tensors(ie)
+            ie = HipCLIPVision(sd_ie, device) if any("vision_model" in k for k in sd_ie) else HipDinov2(sd_ie, device)
+        pipe = cls(cfg, tensors(unet), scheduler=scheduler, vae=hv, device=device, image_encoder=ie, text_encoder=encs[0],
+                   text_encoder_2=encs[1], tokenizer=toks[0], tokenizer_2=toks[1])
+        if aggregator is not None:
+            pipe.aggregator.load_state_dict(tensors(aggregator))
+        return pipe
 
     def to(self, *a, **k):
         return self

@@ -221,3 +221,21 @@ def test_copy_state_refreshes_in_place_and_reports_mismatches():
         other = mk(2.0)
         mutate(other)
         assert not _copy_state(mk(1.0), other)
+
+
+def test_unet_config_from_a_diffusers_config_mapping():
+    """`loaders.unet_config_from_dict`: the SDXL-base `unet/config.json` values give the SDXL geometry; other head sizes are refused."""
+    from instantir_amd import loaders
+    from instantir_amd.config import UNetConfig
+    sdxl = dict(block_out_channels=[320, 640, 1280], down_block_types=["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+                transformer_layers_per_block=[1, 2, 10], attention_head_dim=[5, 10, 20], cross_attention_dim=2048, layers_per_block=2,
+                addition_embed_type="text_time", addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816,
+                in_channels=4, out_channels=4, norm_num_groups=32)
+    got, want = loaders.unet_config_from_dict(sdxl), UNetConfig.sdxl()
+    for f in ("block_out_channels", "transformer_depth", "layers_per_block", "cross_attention_dim", "addition_time_embed_dim", "pooled_dim",
+              "norm_groups", "in_channels", "out_channels"):
+        assert getattr(got, f) == getattr(want, f), f
+    with pytest.raises(ValueError):
+        loaders.unet_config_from_dict(dict(sdxl, attention_head_dim=8))              # head_dim 40 / 80 / 160
+    with pytest.raises(ValueError):
+        loaders.unet_config_from_dict(dict(sdxl, addition_embed_type="text"))

@@ -426,3 +426,28 @@ def test_step_graphs_are_reused_across_calls(env, monkeypatch):
     fresh = _pipe(cfg, sd, sda, lora, DDIMScheduler())
     assert torch.equal(_call(fresh, inp_b, **kw), b1)
     assert torch.equal(_call(fresh, inp_c, num_inference_steps=4, guidance_scale=1.0), c1)
+
+
+def test_from_modules_matches_the_state_dict_constructor(env):
+    """`InstantIRPipeline.from_modules(...)` -- the reference constructor's signature (pipelines/sdxl_instantir.py:303-322) fed with
+    module objects (anything with `.state_dict()` / `.config`) -- builds the same pipeline as the state-dict constructor."""
+    from instantir_amd.pipeline import InstantIRPipeline
+    from instantir_amd.schedulers import DDIMScheduler
+    cfg, sd, sda, lora, inp = env
+
+    class Mod:                       # stand-in for a diffusers module: tensors + (optionally) a config object
+        def __init__(self, tensors, **config):
+            self._t = tensors
+            if config:
+                self.config = type("Config", (), config)()
+
+        def state_dict(self):
+            return self._t
+
+    pipe = InstantIRPipeline.from_modules(unet=Mod(sd), aggregator=Mod(sda), scheduler=DDIMScheduler(), unet_config=cfg)
+    pipe.prepare_previewers(lora, lora_alpha=16)
+    ref = _pipe(cfg, sd, sda, lora, DDIMScheduler())
+    kw = dict(num_inference_steps=3, guidance_scale=7.0)
+    assert torch.equal(_call(pipe, inp, **kw), _call(ref, inp, **kw))
+    with pytest.raises(ValueError):
+        InstantIRPipeline.from_modules(scheduler=DDIMScheduler())
