@@ -15,11 +15,14 @@ def denoise(P, PA, lora, cfg, lq, prompt_embeds, pooled, image_embeds, *, negati
             init_noise=None, step_noises=None, controlnet_conditioning_scale=1.0, control_guidance_start=0.0,
             control_guidance_end=1.0, preview_start=0.0, preview_end=1.0, use_previewer=True, trace=None,
             guidance_rescale=0.0, negative_time_ids=None, adastep_restore=False, reference_latents=None,
-            denoising_end=None, timesteps=None):
+            denoising_end=None, timesteps=None, resume=None, on_step=None):
     """Returns the final latents (B,4,h,w).  `lq`: LQ latent (B,4,h,w); `image_embeds`: (2,B,S,E) [neg;pos] under CFG
     (pipelines/sdxl_instantir.py:700-707) else (1,B,S,E).  `trace` (dict) collects per-step tensors when given.
     The loop body follows :1497-1660 statement by statement, including the quirk that a step which skips the
-    previewer / Aggregator re-scales the PREVIOUS step's already scaled residuals (:1602-1603)."""
+    previewer / Aggregator re-scales the PREVIOUS step's already scaled residuals (:1602-1603).
+    Test plumbing (no reference counterpart): `resume = (x, i0, i1)` continues a chain from the latents `x` it had before step
+    i0 and stops before step i1 (a default-settings chain carries no other state from step to step: tools/parity_chain30.py runs
+    30 steps at 1024^2 in several sittings); `on_step(i, x)` is called with the latents after every step."""
     B = lq.shape[0]
     do_cfg = guidance_scale > 1                                            # :1050-1051
     acp = sched.make_alphas_cumprod()
@@ -52,8 +55,14 @@ def denoise(P, PA, lora, cfg, lq, prompt_embeds, pooled, image_embeds, *, negati
     preview_factor = torch.ones(B, 1, 1, 1)                                # :1490-1492
     down = mid = preview_latent = None
     n_steps = num_inference_steps if timesteps is None else n
-    for i, t in enumerate(ts):
-        t = int(t)
+    i0, i1 = 0, len(ts)
+    if resume is not None:
+        if adastep_restore:
+            raise ValueError("resume: adastep_restore carries previewer_mean / preview_factor across steps")
+        x = x if resume[0] is None else resume[0].clone()               # (None: from the noised LQ latent, i.e. only the stop index applies)
+        i0, i1 = int(resume[1]), min(int(resume[2]), len(ts))
+    for i in range(i0, i1):
+        t = int(ts[i])
         xin = torch.cat([x] * 2) if do_cfg else x                            # :1503
         ada = preview_factor.clamp(0.0, ccs[i])                              # :1538
         cond_scale = ada * keep[i]                                           # :1539
@@ -97,4 +106,6 @@ def denoise(P, PA, lora, cfg, lq, prompt_embeds, pooled, image_embeds, *, negati
             trace.setdefault("cond_scale", []).append(cond_scale.flatten().clone())
             trace.setdefault("preview_factor", []).append(preview_factor.flatten().clone())
         x = x_next
+        if on_step is not None:
+            on_step(i, x)
     return x
