@@ -239,3 +239,30 @@ def test_unet_config_from_a_diffusers_config_mapping():
         loaders.unet_config_from_dict(dict(sdxl, attention_head_dim=8))              # head_dim 40 / 80 / 160
     with pytest.raises(ValueError):
         loaders.unet_config_from_dict(dict(sdxl, addition_embed_type="text"))
+
+
+def test_oracle_chain_resumed_in_sittings_equals_one_chain():
+    """`oracle.pipeline.denoise(resume=, on_step=)` (what tools/parity_chain30.py relies on to run 30 full-size steps across several
+    GPU-box calls): a DDIM chain stopped after 3 of 6 steps and continued from the saved latents is bit-identical to the one chain."""
+    from instantir_amd import weights as W
+    from instantir_amd.config import UNetConfig
+    from oracle import pipeline as OP
+    cfg = UNetConfig.tiny()
+    P = {k: v.float() for k, v in W.synth_state_dict(W.unet_specs(cfg), 11).items()}
+    PA = {k: v.float() for k, v in W.synth_state_dict(W.aggregator_specs(cfg), 12).items()}
+    L = {k: v.float() for k, v in W.synth_state_dict(W.lora_specs(cfg), 13).items()}
+    L["scaling"] = 2.0
+    g = torch.Generator().manual_seed(1)
+    B, H = 1, 8
+    lq = torch.randn(B, 4, H, H, generator=g)
+    pe, po = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g), torch.randn(B, cfg.pooled_dim, generator=g)
+    im = torch.randn(2, B, cfg.resampler.seq_len, cfg.resampler.embedding_dim, generator=g)
+    kw = dict(negative_prompt_embeds=pe * 0.5, negative_pooled=po * 0.5, init_noise=torch.randn(B, 4, H, H, generator=g),
+              num_inference_steps=6, guidance_scale=7.0)
+    full = OP.denoise(P, PA, L, cfg, lq, pe, po, im, **kw)
+    st = {}
+    OP.denoise(P, PA, L, cfg, lq, pe, po, im, resume=(None, 0, 3), on_step=lambda i, x: st.update(x=x.clone(), n=i + 1), **kw)
+    assert st["n"] == 3
+    assert torch.equal(OP.denoise(P, PA, L, cfg, lq, pe, po, im, resume=(st["x"], 3, 6), **kw), full)
+    with pytest.raises(ValueError):
+        OP.denoise(P, PA, L, cfg, lq, pe, po, im, resume=(st["x"], 3, 6), adastep_restore=True, **kw)
