@@ -144,6 +144,18 @@ for (Rx, Tx, hx) in [(2, 1024, 20), (2, 4096, 10)]:
         xa_segs.append((rnd(Rx * Lx, Cx), Lx, rnd(Cx, Rx * tpx), tpx, Lx))
     screen(f"gemm + cross-attention epilogue R={Rx} T={Tx} heads={hx}",
            lambda o: ops.gemm(xa_a, xa_w, o, epi=ops.EPI_XATTN, xattn=(xa_segs, Tx)), [(Rx * Tx, Cx)])
+# both operands fp8 (configs[4] build): GEMM (4-wave one-per-CU tile, 8-wave tile, fp8 result), LayerNorm and attention storing fp8
+for (Mf, Nf, Kf, tile_f, geglu_f, out8) in [(2048, 1280, 1280, 0, False, False), (4096, 1280, 5120, 0, False, False), (4096, 10240, 1280, 91, True, True),
+                                          (16384, 5120, 640, 0, True, True)]:
+    fa8, fsa = ops.quantize_fp8_tensor(rnd(Mf, Kf))
+    fw, fb = rnd(Nf, Kf, scale=Kf ** -0.5), rnd(Nf)
+    if geglu_f:
+        fw, fb = pair_rows(fw[:Nf // 2], fw[Nf // 2:]), pair_rows(fb[:Nf // 2], fb[Nf // 2:])
+    fw8 = ops.Fp8Weight(*ops.quantize_fp8_rows(fw))
+    screen(f"gemm fp8 x fp8 {Mf}x{Nf}x{Kf} tile {tile_f}{' GEGLU' if geglu_f else ''}{' -> fp8' if out8 else ''}",
+           lambda o: ops.gemm_fp8(fa8, fw8, o, a_scale=fsa, bias=fb, tile=tile_f, epi=ops.EPI_GEGLU if geglu_f else ops.EPI_PLAIN),
+           [(Mf, Nf // 2 if geglu_f else Nf)], dtype=torch.uint8 if out8 else torch.half)
+screen("layernorm 2048x1280 -> fp8", lambda o: ops.layernorm(lx, o, lg, lb, 1e-5), [(2048, 1280)], dtype=torch.uint8)
 tx = rnd(154, 1280)
 screen("transpose 154x1280 -> (1280, 160)", lambda o: ops.transpose(tx, o, 160), [(1280, 160)])
 # adaLN batch: 8 jobs of the step's geometry (2 rows x 64 IP tokens, C = 1280 / 640), half of them transposed
