@@ -454,8 +454,9 @@ class InstantIRPipeline:
         """LCM one-step restoration with the previewer LoRA, no CFG (guidance 1.0): noise the LQ latent to `timestep`
         (`prepare_latents` there = scheduler.add_noise), ONE UNet pass with the LoRA enabled, `LCMSingleStepScheduler.step`
         (schedulers/lcm_single_step_scheduler.py:421-489), VAE decode.  `fp8=True` (BASELINE configs[4]): the transformer
-        blocks' linear layers of that pass run on fp8-E4M3 weights (per-output-channel scales, activations converted in the
-        GEMM, `v_mfma_f32_16x16x32_fp8_fp8`) -- a third weight set, built on first use; its tolerance is its own."""
+        blocks' linear layers of that pass run on fp8-E4M3 weights (per-output-channel scales) AND fp8 activations, stored as
+        such by the LayerNorm / attention / GEGLU launch that produces them (`ops.gemm_fp8`, `v_mfma_f32_16x16x32_fp8_fp8`; round 3) --
+        a third weight set, built on first use; its tolerance is its own (45.8 dB against the fp32 oracle at SDXL shapes)."""
         from .engine import CPAD, F16
         if self._lora is None:
             raise RuntimeError("restore_single_step needs the previewer LoRA: call prepare_previewers(...)")

@@ -196,3 +196,56 @@ def test_fp8_activation_stores_match_in_register_conversion_full_shapes(monkeypa
     from conftest import record_psnr
     record_psnr("fullsize.fp8_act_vs_register_conversion", p)
     assert p >= 50.0, p
+
+
+def test_config4_single_step_restoration_full_shapes():
+    """BASELINE configs[4] at FULL SDXL shapes and 1024 x 1024: LQ latent noised to t = 999, ONE previewer-LoRA UNet pass, LCM one-step
+    x0, no CFG -- fp16 build and fp8 build (fp8 weights AND stored fp8 activations on the transformer linears) against the CPU
+    fp32 oracle.  The fp8 tolerance is its own (3 mantissa bits; the reference has no fp8 path): measured 45.8 dB, >= 40 asserted;
+    the fp16 path (measured 76.4 dB) holds the north-star 50 dB."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from instantir_amd import lib, weights as W
+    from instantir_amd.config import UNetConfig
+    from instantir_amd.pipeline import InstantIRPipeline
+    from instantir_amd.schedulers import DDPMScheduler
+    from oracle import nets, sched
+    lib.load()
+    dev = torch.device("cuda:0")
+    cfg = UNetConfig.sdxl()
+    sd = W.synth_state_dict(W.unet_specs(cfg), 1234, device=dev)
+    lora = W.synth_state_dict(W.lora_specs(cfg), 1236, device=dev)
+    g = torch.Generator().manual_seed(44)
+    B, H, alpha = 1, 128, 8
+    lq = torch.randn(B, 4, H, H, generator=g) * 0.8
+    pe = torch.randn(B, 77, 2048, generator=g).half().float()
+    pooled = torch.randn(B, 1280, generator=g).half().float()
+    feats = torch.randn(1, B, 257, 1024, generator=g).half().float()
+    noise = torch.randn(B, 4, H, H, generator=g)
+    pipe = InstantIRPipeline(cfg, sd, scheduler=DDPMScheduler(), device=dev)
+    pipe.prepare_previewers(lora, lora_alpha=alpha)
+    kw = dict(ip_adapter_image_embeds=[feats], init_noise=noise, output_type="latent")
+    got16 = pipe.restore_single_step(lq, pe, pooled, **kw).images.float().cpu()
+    got8 = pipe.restore_single_step(lq, pe, pooled, fp8=True, **kw).images.float().cpu()
+    assert pipe._unet_prev8.fp8_act
+    torch.set_num_threads(_host_cores())
+    P = {k: v.float().cpu() for k, v in sd.items()}
+    L = {k: v.float().cpu() for k, v in lora.items()}
+    L["scaling"] = alpha / cfg.lora_rank
+    del sd, lora, pipe
+    torch.cuda.empty_cache()
+    acp = sched.make_alphas_cumprod()
+    with torch.no_grad():
+        x = sched.add_noise(acp, lq, noise, [999] * B)
+        tid = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]]).repeat(B, 1)
+        ip = nets.image_projection(P, [feats], cfg.resampler, L)[0]
+        want = sched.lcm_step(acp, nets.unet_forward(P, cfg, x, 999, pe, pooled, tid, ip, lora=L), 999, x)
+    ps = {}
+    for name, got in (("fp16", got16), ("fp8", got8)):
+        mse = ((got - want) ** 2).mean().item()
+        ps[name] = 10 * math.log10(want.abs().max().item() ** 2 / max(mse, 1e-30))
+    print(f"configs[4] single step, SDXL shapes 1024px: fp16 {ps['fp16']:.1f} dB, fp8 weights + activations {ps['fp8']:.1f} dB vs CPU fp32 oracle")
+    from conftest import record_psnr
+    record_psnr("fullsize.config4.fp16", ps["fp16"])
+    record_psnr("fullsize.config4.fp8", ps["fp8"])
+    assert torch.isfinite(got8).all() and ps["fp16"] >= 50.0 and ps["fp8"] >= 40.0, ps
