@@ -334,7 +334,9 @@ class InstantIRPipeline:
         self._loop_cache = None                      # drop the old graphs before building the new ones
         loop = _DenoiseLoop(self, B, rep, Hl, Wl, st, st_prev, st_agg, lq, reference_latents, previewer_scheduler,
                             guidance_rescale=guidance_rescale)
-        self._loop_cache = (key, loop)
+        # the entry keeps the engines alive: `id()` in the key can then not be re-issued to a NEW engine (adapter switch, LoRA
+        # scale change) while graphs captured on the old one's arena and weights are still cached
+        self._loop_cache = (key, loop, nets)
         return loop
 
     # ---- input checks (pipelines/sdxl_instantir.py:749-864, the conditions that apply to tensor inputs) ----
