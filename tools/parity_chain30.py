@@ -37,6 +37,8 @@ def psnr(got, want):
 
 t00 = time.time()
 os.makedirs(a.out, exist_ok=True)
+stop = threading.Event()          # heartbeat: an oracle step at 2048^2 outlasts the runner's 7-minute silence limit
+threading.Thread(target=lambda: [print(f"[heartbeat {time.time() - t00:.0f} s]", flush=True) for _ in iter(lambda: stop.wait(60), True)], daemon=True).start()
 lib.load()
 dev = torch.device("cuda:0"); cfg = UNetConfig.sdxl()
 sd = W.synth_state_dict(W.unet_specs(cfg), 1234, device=dev); sda = W.synth_state_dict(W.aggregator_specs(cfg), 1235, device=dev)
@@ -76,6 +78,7 @@ def on_step(i, x):
 with torch.no_grad():
     OP.denoise(P, PA, L, cfg, lq, pe, pooled, feats, negative_prompt_embeds=npe, negative_pooled=npooled, init_noise=noise,
                num_inference_steps=a.steps, guidance_scale=7.0, sampler="ddim", resume=(state["x"], k0, k1), on_step=on_step)
+stop.set()
 if state["next"] >= a.steps:
     print(f"RESULT size={a.size} cfg=7.0 steps={a.steps}: final latents HIP vs CPU fp32 oracle {state['psnr'][-1]:.1f} dB; "
           f"per step min {min(state['psnr']):.1f} dB; curve {[round(v, 1) for v in state['psnr']]}", flush=True)
