@@ -507,6 +507,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         char* vl = smem + 2 * KIMG;
         const int tk0 = g.xa_tk[0], tk1 = g.xa_tk[1];
         const int vch0 = (tk0 + 7) >> 3, vch1 = (tk1 + 7) >> 3;               // readable 16-byte chunks of a V^T row
+#ifndef IIR_DBG_XA_NOSTAGE      // (timing experiments, results wrong: -DIIR_DBG_XA_NOSTAGE / _NOCOMPUTE / _NOSOFTMAX price the parts of this tail)
 #pragma unroll
         for (int it = 0; it < 9; ++it) {          // K rows: [0, 80) text keys, [80, 144) IP keys; rows past Tkv repeat the last key (masked below)
             const int s = (it * 4 + wave) * 64 + lane, hh = s >= 1152 ? 1 : 0, sl = s - hh * 1152;
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
                                  : g.xa_vt[0] + rowv * g.xa_ldvt[0] + (long)img * g.xa_vb[0]) + cc * 8;
             glds16(src, vl + (it * 4 + wave) * 1024);
         }
+#endif
         // q = what the plain epilogue would have stored (LayerNorm fold, bias, fp16 rounding), as MFMA operands
         typedef E E4v __attribute__((ext_vector_type(4)));
         E8 qf[MI][2];
@@ -540,7 +542,8 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
                 for (int t = 0; t < 4; ++t)
                     qf[i][j >> 1][(j & 1) * 4 + t] = (E)fmaf(acc[i][j][t], rs.x, fmaf(rs.y, pre_c1[j][t], (float)pre_c0[j][t]));
         }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");         // K / V images complete
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");         // K / V images complete (waiting for K alone here and for V^T before P V measured no better)
+#ifndef IIR_DBG_XA_NOCOMPUTE
         // S = q K^T: 9 key blocks of 16 (5 text, 4 IP), contraction over d in the accumulator's order
         f32x4 sa[MI][9];
         const char* kh = kl + wn * KIMG;
@@ -564,6 +567,9 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
         }
         // softmax per segment (q carries scale x log2 e: p = exp2(s - max)), normalised, as the P operand of P V
         E8 pf[MI][5];
+#ifdef IIR_DBG_XA_NOSOFTMAX
+        for (int i = 0; i < MI; ++i) for (int kp = 0; kp < 5; ++kp) for (int t = 0; t < 4; ++t) { pf[i][kp][t] = (E)sa[i][2 * kp][t]; pf[i][kp][4 + t] = (E)sa[i][kp < 4 ? 2 * kp + 1 : 8][t]; }
+#else
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             float mx[2] = {-INFINITY, -INFINITY};
@@ -605,6 +611,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
                     pf[i][kp][4 + t] = kb2 < 9 ? (E)(sa[i][kb2 < 9 ? kb2 : 8][t] * sm[kb2 < 5 ? 0 : 1]) : (E)0.f;
                 }
         }
+#endif
         // O = P V: contraction over keys in the order P holds them (key column 16 kb + 4 fq + t: IP keys start at column 80)
         const char* vh = vl + wn * VIMG;
 #pragma unroll
@@ -622,6 +629,7 @@ __global__ __launch_bounds__(128 * WAVES_M * (LW ? 2 : 1), (WAVES_M == 2 ? 2 : 1
                 for (int i = 0; i < MI; ++i) acc[i][j] = ET<E>::mfma16(vf, pf[i][kp], acc[i][j]);
             }
         }
+#endif
 #pragma unroll
         for (int j = 0; j < NI; ++j) {            // the tile now holds finished values: phase 1 adds nothing
             pre_c1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
