@@ -286,7 +286,8 @@ def main():
                 e2e = {"seconds_per_image": round(e2e_s, 4), "images_per_s": round(1.0 / e2e_s, 4), "finite_and_shaped": e2e_ok,
                        "what": "pipe(image=PIL 1024x1024, prompt_ids=..., 30 steps, cfg 7.0, output_type='pt'): DINOv2-L + CLIP-L/bigG + "
                                "Resampler + prepare + loop + VAE encode/decode, second call on the pipeline (a different image and prompt; the "
-                               "step graphs captured by the first call of a geometry are kept, as for every later image of a batch job)"}
+                               "step graphs captured by the first call of a geometry are kept, as for every later image of a batch job; the negative prompt is the "
+                               "job's fixed one, so its two CLIP passes come from the per-token-id cache, the new positive prompt is encoded)"}
                 log(f"end-to-end pipe(...) call: {e2e_s:.3f} s per image")
             except Exception as ex:      # (transformers / PIL missing on the box: say so instead of failing the bench line)
                 e2e = {"seconds_per_image": None, "images_per_s": None, "error": f"{type(ex).__name__}: {ex}"[:300]}

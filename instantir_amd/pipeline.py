@@ -136,6 +136,7 @@ class InstantIRPipeline:
         self._unet = self._unet_prev = self._agg = self._unet_prev8 = None
         self._graphs = {}
         self._loop_cache = None                     # (key, _DenoiseLoop) of the last call: see _loop_for
+        self._prompt_cache = {}                     # (token ids, encoders) -> (prompt_embeds, pooled): see encode_prompt
         self.use_graphs = True
         self.overlap_streams = True
         self.overlap_sft = os.environ.get("IIR_OVERLAP_SFT", "1") != "0"     # shallow SFT heads beside the decoder's first up block
@@ -398,7 +399,19 @@ class InstantIRPipeline:
             prompt_ids_2 = ids_of(prompt_2 if prompt_2 is not None else prompt, self.tokenizer_2 or self.tokenizer)
         if prompt_ids_2 is None:
             prompt_ids_2 = prompt_ids
-        pe, pooled = encode_prompt_ids(self.text_encoder, self.text_encoder_2, prompt_ids, prompt_ids_2, clip_skip)
+        def encode(ids, ids2, skip):
+            # A batch job restores every image under the SAME prompt (infer.py:211-222): the two CLIP passes (~20 ms per prompt at
+            # SDXL size) are kept per token-id pair -- the encoders are deterministic, the cached tensors are never written to.
+            key = (ids.cpu().numpy().tobytes(), ids2.cpu().numpy().tobytes(), tuple(ids.shape), skip, id(self.text_encoder), id(self.text_encoder_2))
+            hit = self._prompt_cache.get(key)
+            if hit is None or hit[2] is not self.text_encoder or hit[3] is not self.text_encoder_2:
+                hit = (*encode_prompt_ids(self.text_encoder, self.text_encoder_2, ids, ids2, skip), self.text_encoder, self.text_encoder_2)
+                if len(self._prompt_cache) >= 8:
+                    self._prompt_cache.pop(next(iter(self._prompt_cache)))
+                self._prompt_cache[key] = hit
+            return hit[0], hit[1]
+
+        pe, pooled = encode(prompt_ids, prompt_ids_2, clip_skip)
         npe = npooled = None
         if do_cfg:
             if negative_prompt_ids is None and negative_prompt is not None:
@@ -409,8 +422,7 @@ class InstantIRPipeline:
                 npe, npooled = torch.zeros_like(pe), torch.zeros_like(pooled)
             else:
                 # (the reference always takes hidden_states[-2] for the negative prompt, :586: clip_skip is not applied)
-                npe, npooled = encode_prompt_ids(self.text_encoder, self.text_encoder_2, negative_prompt_ids,
-                                                 negative_prompt_ids_2 if negative_prompt_ids_2 is not None else negative_prompt_ids)
+                npe, npooled = encode(negative_prompt_ids, negative_prompt_ids_2 if negative_prompt_ids_2 is not None else negative_prompt_ids, None)
         return pe, npe, pooled, npooled
 
     def encode_image(self, image):

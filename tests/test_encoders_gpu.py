@@ -146,6 +146,23 @@ def test_pipeline_with_encoders_attached():
     b = p2(prompt_embeds=pe, pooled_prompt_embeds=pooled, ip_adapter_image_embeds=feats,
            previewer_scheduler=LCMSingleStepScheduler.from_config(p2.scheduler.config), **common).images
     assert torch.isfinite(a).all() and torch.equal(a, b)
+    # the text encodings are kept per token-id pair (a batch job uses one prompt): same ids -> no second CLIP pass, same
+    # tensors; other ids or another encoder object -> a fresh pass
+    calls = []
+    real = te1.__class__.__call__
+    te1.__class__.__call__ = lambda self_, *aa, **kk: (calls.append(1), real(self_, *aa, **kk))[1]
+    try:
+        pe2, _, pooled2, _ = p1.encode_prompt(prompt_ids=ids, do_cfg=True)
+        assert not calls and torch.equal(pe2, pe) and torch.equal(pooled2, pooled)
+        ids_b = ids.clone()
+        ids_b[0, 1] = (int(ids[0, 1]) + 1) % 90 + 2
+        pe3, _, _, _ = p1.encode_prompt(prompt_ids=ids_b, do_cfg=True)
+        assert len(calls) == 2 and not torch.equal(pe3, pe)           # both encoders ran once
+        p1.text_encoder = HipCLIPText(mk(), "cuda:0", eos_token_id=99)
+        pe4, _, _, _ = p1.encode_prompt(prompt_ids=ids, do_cfg=True)
+        assert len(calls) == 4 and not torch.equal(pe4, pe)
+    finally:
+        te1.__class__.__call__ = real
 
 
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
